@@ -1,0 +1,137 @@
+/* tvae_hip.h — C ABI of libtvae_hip.so: the latent bottleneck + MMD hot path of
+ * Transformer-VAE on MI355X (gfx950).
+ *
+ * The reference (Fraser-Greenlee/transformer-vae) is pure Python and has no FFI layer;
+ * the seam this library plugs into is the module interface of
+ * transformer_vae/autoencoders.py.  Each entry point below names the reference lines
+ * whose arithmetic it replaces.  The Python host (transformer_vae_amd/) binds these
+ * symbols with ctypes and wraps them in torch.autograd.Functions; a reference
+ * maintainer would bind them the same way.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; sizes are element
+ *     counts (int64_t); matrices are row-major with the innermost dimension contiguous;
+ *   - `dtype` is the element type of activations AND parameters of that call
+ *     (TVAE_F32 or TVAE_BF16); accumulation is always fp32 (fp32-input MFMA), the
+ *     MMD reductions are fp64;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Kernels are
+ *     enqueued on it; no entry point synchronises, allocates or frees device memory —
+ *     scratch comes from the caller as `workspace`, sized by the matching
+ *     *_workspace_bytes() query (a host-only function);
+ *   - return value: 0 on success, a TVAE_ERR_* code otherwise; tvae_last_error()
+ *     returns a thread-local, human-readable message for the last failure;
+ *   - no global mutable state: concurrent calls from different host threads on
+ *     different streams (nn.DataParallel replicas) are safe.
+ */
+#ifndef TVAE_HIP_H
+#define TVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TVAE_F32 0
+#define TVAE_BF16 1
+
+#define TVAE_OK 0
+#define TVAE_ERR_ARG 1         /* bad shape / null pointer / unsupported size */
+#define TVAE_ERR_HIP 2         /* a HIP runtime call failed */
+#define TVAE_ERR_WORKSPACE 3   /* workspace too small */
+
+/* Library ABI version (major*1000 + minor). */
+int tvae_version(void);
+/* Thread-local message describing the last error returned on this host thread. */
+const char* tvae_last_error(void);
+
+/* ---------------------------------------------------------------------------------
+ * Latent encoder.  Replaces LatentEncoderNTokens.forward, autoencoders.py:21-22:
+ *     latent = tanh(Linear(d_model -> L)(h))[:, :n_tokens, :]
+ * computed slice-first: only the first n_eff = min(n_tokens, S) tokens of every
+ * sequence are projected (bit-identical values, S/n times less work).
+ *   h      (B, S, d) with element strides (h_stride_b, h_stride_s, 1)
+ *   We     (L, d), be (L)            nn.Linear weight / bias
+ *   latent (B, n_eff, L) contiguous  output
+ *   workspace: optional split-K scratch (may be NULL / 0: the product is then not split)
+ * ------------------------------------------------------------------------------- */
+int64_t tvae_encode_fwd_workspace_bytes(int64_t B, int64_t n_eff, int64_t d, int64_t L);
+int tvae_encode_fwd(const void* h, int64_t h_stride_b, int64_t h_stride_s,
+                    const void* We, const void* be, void* latent,
+                    int64_t B, int64_t n_eff, int64_t d, int64_t L,
+                    int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Backward of the encoder (autograd of autoencoders.py:22).
+ *   d_latent (B, n_eff, L)  total cotangent of `latent`
+ *   latent   (B, n_eff, L)  saved forward output (tanh'(x) = 1 - latent^2)
+ *   dh       (B, S, d) contiguous, nullable: rows [0,n_eff) of every sequence receive
+ *            d_pre @ We, rows [n_eff, S) are zero-filled by this call (the reference's
+ *            slice backward yields exact zeros there)
+ *   dWe (L, d), dbe (L)     nullable (skipped when null) */
+int64_t tvae_encode_bwd_workspace_bytes(int64_t B, int64_t n_eff, int64_t d, int64_t L);
+int tvae_encode_bwd(const void* d_latent, const void* latent,
+                    const void* h, int64_t h_stride_b, int64_t h_stride_s,
+                    const void* We, void* dh, void* dWe, void* dbe,
+                    int64_t B, int64_t S, int64_t n_eff, int64_t d, int64_t L,
+                    int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Latent decoder.  Replaces LatentDecoderNTokens.forward (autoencoders.py:38-39) and,
+ * when gamma != NULL, LatentDecoderFunnelNorm.forward (autoencoders.py:66-67):
+ *     r = latent @ Wd^T + bd          (Wd == NULL: identity, the L == d_model case
+ *                                      of autoencoders.py:32-34; then L must equal d)
+ *     recon = LayerNorm_d(r; gamma, beta, eps)   or   recon = r
+ *   latent (N, L)  N = B * n_eff
+ *   Wd (d, L), bd (d), gamma (d), beta (d)
+ *   recon (N, d) output
+ *   pre_norm (N, d): r, saved for backward; required iff gamma != NULL and Wd != NULL
+ *            (with Wd == NULL the caller's `latent` is r)
+ *   mean, rstd (N) fp32: LayerNorm statistics, required iff gamma != NULL */
+int64_t tvae_decode_fwd_workspace_bytes(int64_t N, int64_t L, int64_t d);
+int tvae_decode_fwd(const void* latent, const void* Wd, const void* bd,
+                    const void* gamma, const void* beta, float eps,
+                    void* recon, void* pre_norm, float* mean, float* rstd,
+                    int64_t N, int64_t L, int64_t d, int dtype,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Backward of the decoder.
+ *   d_recon (N, d) cotangent;  pre_norm/mean/rstd as saved by tvae_decode_fwd
+ *   d_latent (N, L) output (nullable);  dWd (d, L), dbd (d), dgamma (d), dbeta (d) nullable */
+int64_t tvae_decode_bwd_workspace_bytes(int64_t N, int64_t L, int64_t d);
+int tvae_decode_bwd(const void* d_recon, const void* latent, const void* Wd,
+                    const void* gamma, const void* pre_norm, const float* mean, const float* rstd,
+                    void* d_latent, void* dWd, void* dbd, void* dgamma, void* dbeta,
+                    int64_t N, int64_t L, int64_t d, int dtype,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * MMD regulariser, forward and gradient in one pass.  Replaces
+ * EncoderDecoderVAE._compute_kernel/_compute_mmd/_regularliser_loss
+ * (autoencoders.py:117-136) and their autograd:
+ *     K(a,b) = exp(-||a-b||^2 / D^2);  MMD = mean Kyy + mean Kzz - 2 mean Kyz
+ * evaluated as tiled Gram products on the matrix cores with E = K - 1 = expm1(-t)
+ * accumulated instead of K (the '+1's cancel exactly), never materialising N x N.
+ *
+ * Row-sharded form: this call handles rows [row_offset, row_offset + n_rows) of the
+ * kernel matrices against ALL n_total columns (single GPU: row_offset 0, n_rows =
+ * n_total).  z_all / y_all hold all n_total latent / prior rows (after the
+ * all-gather), both (n_total, D), same dtype.
+ *   sums3  double[3] out: sum of E over (local z rows x all z), (local z rows x all y),
+ *          (local y rows x all y).  Adding sums3 over a partition of the rows gives the
+ *          global sums:  MMD = (S_yy + S_zz - 2 S_zy) / n_total^2.
+ *   loss   float out, nullable: loss_scale * (S_yy + S_zz - 2 S_zy) of THIS call's rows
+ *          (single GPU: pass loss_scale = n_tokens / (B * n_total^2) to get reg_loss)
+ *   d_z    (n_rows, D) out, nullable: grad_scale * sum-form gradient for the local rows,
+ *          complete (needs no exchange):  pass grad_scale = 4 n / (B N^2 D^2) for
+ *          d reg_loss / d latent  (SURVEY.md 8a).  Written in `dtype`. */
+int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad);
+int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all,
+                     int64_t n_total, int64_t row_offset, int64_t n_rows, int64_t D, int dtype,
+                     double* sums3, float* loss, double loss_scale,
+                     void* d_z, double grad_scale,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TVAE_HIP_H */

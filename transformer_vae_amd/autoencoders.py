@@ -1,0 +1,178 @@
+"""MI355X-native latent bottleneck: drop-in for ``transformer_vae.autoencoders``.
+
+Same class names, constructor signatures, registry keys, parameter names and forward
+contract as the reference (citations: transformer_vae/autoencoders.py), so
+``Funnel_T5_VAE_Model`` (model.py:84-88, 258-260) and ``VAE_Trainer`` (trainer.py:347) can
+use these modules unchanged and checkpoints interchange:
+
+    vae.encoder.token_to_latent.{weight,bias}      (L, d) / (L,)
+    vae.decoder.latent_to_token.{weight,bias}      (d, L) / (d,)     absent when L == d
+    vae.decoder.norm.{weight,bias}                 (d,)              default decoder only
+
+What differs is where the arithmetic runs: every forward/backward below calls the
+hand-written gfx950 kernels through ``functional`` (C ABI in include/tvae_hip.h).
+Additions that default to the reference's behaviour:
+  * ``true_samples=`` on ``EncoderDecoderVAE.forward`` injects the prior sample (the
+    reference draws ``torch.randn(latent.size())`` inside ``_regularliser_loss``, :135);
+  * ``mmd_scope="global"`` + ``process_group`` evaluate the MMD of the global batch,
+    row-sharded over ranks (distributed.py); ``"local"`` is what the reference does under DDP.
+"""
+from __future__ import annotations
+
+import logging
+
+import torch
+from torch import nn
+
+from . import functional as F
+from .model_outputs import BaseVAE_Output
+
+logger = logging.getLogger(__name__)
+
+
+class LatentEncoderNTokens(nn.Module):
+    """Converts the first N hidden tokens into N separate latent codes (autoencoders.py:11-22)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.token_to_latent = nn.Linear(config.t5.d_model, config.latent_size)
+        self.n_tokens = config.n_latent_tokens
+        self.tanh = nn.Tanh()   # kept for module-tree parity; tanh is fused into the projection kernel
+
+    def forward(self, encoding) -> torch.Tensor:
+        return F.latent_encode(encoding, self.token_to_latent.weight, self.token_to_latent.bias, self.n_tokens)
+
+
+# alias for the name used by other revisions of the upstream project
+LatentEncoderLargeTanh = LatentEncoderNTokens
+
+
+class LatentDecoderNTokens(nn.Module):
+    """Latent tokens -> full token hidden states (autoencoders.py:25-39).
+
+    When latent_size == d_model the reference installs an identity (and no parameters); so do we."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.latent_size = config.latent_size
+        if self.latent_size == config.t5.d_model:
+            logger.warning("Latent decoder is not rescaling the latent code.")
+            self.latent_to_token = None
+        else:
+            self.latent_to_token = nn.Linear(self.latent_size, config.t5.d_model)
+
+    def _linear_params(self):
+        if self.latent_to_token is None:
+            return None, None
+        return self.latent_to_token.weight, self.latent_to_token.bias
+
+    def forward(self, latent) -> torch.Tensor:
+        w, b = self._linear_params()
+        if w is None:
+            return latent          # identity, exactly like the reference's `lambda x: x`
+        return F.latent_decode(latent, w, b)
+
+
+class LatentDecoderFunnelNorm(LatentDecoderNTokens):
+    """Linear + nn.LayerNorm(funnel.d_model, funnel.layer_norm_eps), fused (autoencoders.py:58-67)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.norm = nn.LayerNorm(config.funnel.d_model, config.funnel.layer_norm_eps)
+
+    def forward(self, latent) -> torch.Tensor:
+        w, b = self._linear_params()
+        return F.latent_decode(latent, w, b, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class LatentDecoderT5Norm(LatentDecoderNTokens):
+    """Linear + a stock HF ``T5LayerFF`` block with dropout forced to 0 (autoencoders.py:42-55).
+
+    The feed-forward block is third-party code in the reference too; only the linear runs on
+    our kernels."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        from transformers.models.t5.modeling_t5 import T5LayerFF
+        t_config = config.t5
+        dropout_rate = t_config.dropout_rate
+        t_config.dropout_rate = 0
+        self.norm = T5LayerFF(t_config)
+        t_config.dropout_rate = dropout_rate
+
+    def forward(self, latent) -> torch.Tensor:
+        return self.norm(super().forward(latent))
+
+
+# alias for the name used in the north-star description
+LatentDecoder = LatentDecoderFunnelNorm
+
+VAE_ENCODER_MODELS = {
+    "": LatentEncoderNTokens,
+}
+VAE_DECODER_MODELS = {
+    "": LatentDecoderFunnelNorm,
+    "t5_norm": LatentDecoderT5Norm,
+    "no_norm": LatentDecoderNTokens,
+}
+
+
+class EncoderDecoderVAE(nn.Module):
+    """An MMD-VAE bottleneck used between an encoder and a decoder stack (autoencoders.py:80-136)."""
+
+    batch_size = None
+
+    def __init__(self, encoder, decoder, use_reg_loss=True, mmd_scope="local", process_group=None,
+                 compensate_ddp_mean=False):
+        super().__init__()
+        if mmd_scope not in ("local", "global"):
+            raise ValueError(f"mmd_scope must be 'local' or 'global', got {mmd_scope!r}")
+        self.encoder = encoder
+        self.decoder = decoder
+        self.use_reg_loss = use_reg_loss
+        self.mmd_scope = mmd_scope
+        self.process_group = process_group
+        self.compensate_ddp_mean = compensate_ddp_mean
+
+    def _model_forward(self, encoding, latent=None):
+        if latent is None:
+            latent = self.encoder(encoding)
+        return self.decoder(latent), latent
+
+    def forward(self, input_encoding=None, latent=None, skip_reg_loss=False, true_samples=None):
+        if input_encoding is None and latent is None:
+            raise ValueError("Both `input_encoding` and `latent` sent to VAE are None.")
+        use_reg_loss = self.use_reg_loss and latent is None and skip_reg_loss is False  # don't regularise if given latent
+        recon_encoding, latent = self._model_forward(input_encoding, latent=latent)
+        if use_reg_loss:
+            # each token encoding is a separate latent code (autoencoders.py:110-112)
+            batch_size, n_latents_per_batch, latent_code_dim = latent.size()
+            reg_loss = self._regularliser_loss(latent.reshape(-1, latent_code_dim), batch_size, n_latents_per_batch,
+                                               true_samples)
+        else:
+            reg_loss = torch.tensor(0, device=latent.device)
+        return BaseVAE_Output(latent=latent, reconstructed_encoding=recon_encoding, reg_loss=reg_loss)
+
+    def _compute_mmd(self, x, y):
+        """MMD(x = prior samples, y = latents), unscaled (autoencoders.py:128-132); differentiable in y."""
+        n, dim = y.shape
+        loss, _ = F.mmd_row_block(y, y, x, 0, 1.0 / float(n) ** 2, 4.0 / (float(n) ** 2 * float(dim) ** 2))
+        return loss
+
+    def _regularliser_loss(self, latent, batch_size, n_latents_per_batch, true_samples=None):
+        """MMD(prior, latent) / batch_size * n_latents (autoencoders.py:112, 134-136).
+
+        The 1/batch * n scaling is folded into the kernel's output scale."""
+        if true_samples is None:
+            true_samples = torch.randn(latent.size(), device=latent.device)   # fp32, as the reference (:135)
+        else:
+            true_samples = true_samples.reshape(latent.shape).to(latent.device)
+        if latent.numel() == 0:
+            return torch.zeros((), dtype=torch.float32, device=latent.device)
+        if self.mmd_scope == "global":
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+                from .distributed import sharded_mmd_reg_loss
+                return sharded_mmd_reg_loss(latent, true_samples, batch_size, n_latents_per_batch, self.process_group,
+                                            self.compensate_ddp_mean)
+        return F.mmd_reg_loss(latent, true_samples, batch_size, n_latents_per_batch)

@@ -1,0 +1,209 @@
+// fp32-accurate projection GEMM on the gfx950 matrix cores.
+//
+// Every contraction of the bottleneck (encode, decode, and the four backward products)
+// runs through this one LDS-tiled kernel built on v_mfma_f32_32x32x2_f32: fp32 (or bf16
+// widened to fp32) operands, fp32 accumulate — bit-for-bit an fmaf chain, so the fp32
+// path meets the 1e-5 parity bar without split-precision tricks.
+//
+//   workgroup = 4 waves = one 64x64 tile of C, each wave one 32x32 accumulator
+//   K is walked in 32-deep LDS tiles; operands are stored k-major in LDS ([k][m], ld 65)
+//   so that lane (i = l&31, h = l>>5) of MFMA step s reads A[k=2s+h][i] / B[k=2s+h][j]
+//   with conflict-free ds_read_b32 whatever the layout in HBM was.
+//   Operands may be "row-gathered" (RowMap) — that is how the first-n-token slice of h is
+//   read and how dh[:, :n] is scattered without a copy.
+//   Thin outputs with long K (the weight gradients: K = B*n rows) are split along K over
+//   blockIdx.z into fp32 slabs and summed in a fixed order (deterministic, no atomics).
+#include "tvae_common.h"
+
+namespace tvae {
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = 65;
+
+struct GemmArgs {
+    const void* A; const void* B; void* C; const void* bias; float* slab;
+    int M, N, K, k_per_split, splits;
+    RowMap amap, bmap, cmap;
+    int vecA, vecB;
+};
+
+// Stage a (64 rows x 32 k) operand tile into LDS as tile[k][row].
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void stage_tile(float (*tile)[LDS_LD], const T* __restrict__ P, const RowMap& map,
+                                           int r0, int R, int k0, int kend, bool vec, int tid) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + 256 * j;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!KMAJOR) {
+            const int row = q >> 3, kq = (q & 7) * 4;
+            const int r = r0 + row, k = k0 + kq;
+            if (r < R && k < kend) {
+                const T* p = P + map(r) + k;
+                const int nv = min(4, kend - k);
+                if (vec && nv == 4) load4_vec(p, v); else load4_guard(p, nv, v);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[kq + e][row] = v[e];
+        } else {
+            const int krow = q >> 4, rq = (q & 15) * 4;
+            const int k = k0 + krow, r = r0 + rq;
+            if (k < kend && r < R) {
+                const T* p = P + map(k) + r;
+                const int nv = min(4, R - r);
+                if (vec && nv == 4) load4_vec(p, v); else load4_guard(p, nv, v);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[krow][rq + e] = v[e];
+        }
+    }
+}
+
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
+    __shared__ float As[BK][LDS_LD];
+    __shared__ float Bs[BK][LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+    const int kbeg = z * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const T* __restrict__ A = static_cast<const T*>(a.A);
+    const T* __restrict__ B = static_cast<const T*>(a.B);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage_tile<T, A_KMAJOR>(As, A, a.amap, m0, a.M, k0, kend, a.vecA, tid);
+        stage_tile<T, B_KMAJOR>(Bs, B, a.bmap, n0, a.N, k0, kend, a.vecB, tid);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const float av = As[2 * s + h][wr * 32 + i32];
+            const float bv = Bs[2 * s + h][wc * 32 + i32];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int n = n0 + wc * 32 + i32;
+    if (n >= a.N) return;
+    float bias = 0.f;
+    if (EPI != EPI_NONE && a.splits == 1) bias = to_f32(static_cast<const T*>(a.bias)[n]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= a.M) continue;
+        float v = acc[r];
+        if (a.splits > 1) {
+            a.slab[((long long)z * a.M + m) * a.N + n] = v;
+        } else {
+            if (EPI != EPI_NONE) v += bias;
+            if (EPI == EPI_BIAS_TANH) v = tanhf(v);
+            static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
+        }
+    }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(GemmArgs a) {
+    const long long total = (long long)a.M * a.N;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int m = (int)(idx / a.N), n = (int)(idx % a.N);
+        float v = 0.f;
+        for (int z = 0; z < a.splits; ++z) v += a.slab[(long long)z * total + idx];
+        if (EPI != EPI_NONE) v += to_f32(static_cast<const T*>(a.bias)[n]);
+        if (EPI == EPI_BIAS_TANH) v = tanhf(v);
+        static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
+    }
+}
+
+void choose_split(int M, int N, int K, int* splits, int* k_per_split) {
+    const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int s = 1;
+    if (tiles < 256 && K > 256) {
+        s = (int)((512 + tiles - 1) / tiles);
+        const int max_s = (K + 127) / 128;
+        if (s > max_s) s = max_s;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
+    }
+    int kps = (K + s - 1) / s;
+    kps = (kps + BK - 1) / BK * BK;
+    if (kps < BK) kps = BK;
+    *k_per_split = kps;
+    *splits = (K + kps - 1) / kps;
+    if (*splits < 1) *splits = 1;
+}
+
+template <typename T, bool AK, bool BKM>
+int launch_epi(const GemmArgs& a, int epi, dim3 grid, hipStream_t s) {
+    switch (epi) {
+        case EPI_NONE: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_NONE>), grid, dim3(256), 0, s, a); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_BIAS>), grid, dim3(256), 0, s, a); break;
+        case EPI_BIAS_TANH: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_BIAS_TANH>), grid, dim3(256), 0, s, a); break;
+        default: return fail(TVAE_ERR_ARG, "gemm: bad epilogue %d", epi);
+    }
+    return TVAE_OK;
+}
+
+template <typename T>
+int launch_typed(const GemmDesc& g, GemmArgs& a, hipStream_t s) {
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, a.splits);
+    // the split-K main pass writes raw partials; the epilogue runs in the reduce pass
+    const int epi_main = a.splits > 1 ? EPI_NONE : g.epilogue;
+    int st;
+    if (!g.a_kmajor && !g.b_kmajor) st = launch_epi<T, false, false>(a, epi_main, grid, s);
+    else if (!g.a_kmajor && g.b_kmajor) st = launch_epi<T, false, true>(a, epi_main, grid, s);
+    else if (g.a_kmajor && g.b_kmajor) st = launch_epi<T, true, true>(a, epi_main, grid, s);
+    else return fail(TVAE_ERR_ARG, "gemm: layout (A k-major, B n-major) is not instantiated");
+    TVAE_PROPAGATE(st);
+    if (a.splits > 1) {
+        const long long total = (long long)g.M * g.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        switch (g.epilogue) {
+            case EPI_NONE: hipLaunchKernelGGL((gemm_reduce_slabs_kernel<T, EPI_NONE>), dim3(blocks), dim3(256), 0, s, a); break;
+            case EPI_BIAS: hipLaunchKernelGGL((gemm_reduce_slabs_kernel<T, EPI_BIAS>), dim3(blocks), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((gemm_reduce_slabs_kernel<T, EPI_BIAS_TANH>), dim3(blocks), dim3(256), 0, s, a); break;
+        }
+    }
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+}  // namespace
+
+int64_t gemm_slab_floats(int M, int N, int K) {
+    int s, kps;
+    choose_split(M, N, K, &s, &kps);
+    return s > 1 ? (int64_t)s * M * N : 0;
+}
+
+int gemm_launch(const GemmDesc& g, hipStream_t stream) {
+    if (g.M <= 0 || g.N <= 0) return TVAE_OK;
+    TVAE_REQUIRE(g.K > 0, "gemm: K must be positive (got %d)", g.K);
+    TVAE_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
+    TVAE_REQUIRE(g.epilogue == EPI_NONE || g.bias, "gemm: epilogue needs a bias pointer");
+    GemmArgs a;
+    a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.slab = g.slab;
+    a.M = g.M; a.N = g.N; a.K = g.K;
+    a.amap = g.amap; a.bmap = g.bmap; a.cmap = g.cmap;
+    choose_split(g.M, g.N, g.K, &a.splits, &a.k_per_split);
+    if (a.splits > 1 && (!g.slab || g.slab_floats < (int64_t)a.splits * g.M * g.N)) {
+        a.splits = 1;
+        a.k_per_split = (g.K + BK - 1) / BK * BK;
+    }
+    const size_t align = g.dtype == TVAE_F32 ? 16 : 8;
+    a.vecA = g.amap.vec_ok() && (reinterpret_cast<uintptr_t>(g.A) % align == 0);
+    a.vecB = g.bmap.vec_ok() && (reinterpret_cast<uintptr_t>(g.B) % align == 0);
+    if (g.dtype == TVAE_F32) return launch_typed<float>(g, a, stream);
+    if (g.dtype == TVAE_BF16) return launch_typed<bf16>(g, a, stream);
+    return fail(TVAE_ERR_ARG, "gemm: unknown dtype %d", g.dtype);
+}
+
+}  // namespace tvae

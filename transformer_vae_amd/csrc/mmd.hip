@@ -1,0 +1,488 @@
+// Fused MMD forward + gradient for gfx950 (autoencoders.py:117-136 and its autograd).
+//
+// Math.  With t(a,b) = ||a-b||^2 / D^2, K = exp(-t), E = K - 1 = expm1(-t):
+//   MMD       = [ SS E(y,y) + SS E(z,z) - 2 SS E(y,z) ] / N^2          (the +1's cancel exactly)
+//   dMMD/dz_k = 4/(N^2 D^2) [ -z_k * R_k + (Zsum - Ysum) + G_k ]
+//   R_k = S_p s_p E(z_k,x_p),  G_k = S_p s_p E(z_k,x_p) x_p,  p over all z (s=+1) and all y (s=-1)
+// Working with E keeps every accumulated quantity ~|t| << 1, so the catastrophic
+// cancellation of the reference's "three means near 1" never happens in fp32.
+//
+// Kernel structure (mmd_tile_kernel).  One workgroup = 4 waves owns 32 rows i of the kernel
+// matrix and walks 16-point column tiles p.  The feature dimension is SLICED over the four
+// waves (wave w owns columns [w*SW, (w+1)*SW) of the padded dimension DPAD = 4*SW):
+//   1. each wave stages ITS slice of the 16 x DPAD point tile into a wave-private LDS region
+//      (no workgroup barrier needed for the tile);
+//   2. Gram: S'[p][i] partial over the slice with v_mfma_f32_16x16x4_f32 — A = point tile
+//      from LDS (ds_read_b128, 4 k-steps per read), B = the 32 rows held in registers for the
+//      whole kernel.  k order inside the dot product is permuted identically for A and B;
+//   3. the 4 partial S' tiles are exchanged through LDS (one barrier per tile, double
+//      buffered) and summed in a fixed order, so every wave holds the full S' in the MFMA
+//      C layout (row p = 4*(lane>>4)+reg, column i = lane&15);
+//   4. E' = expm1(-t) in registers (masked at ragged edges), sums in fp64;
+//   5. gradient: acc^T[d][i] += X^T[d][p] * E'[p][i] — the accumulator tile E' is ALREADY in
+//      the B-operand layout of the next MFMA (it sums over E's row index p), so it never
+//      leaves registers; A = the same LDS tile read transposed (conflict-free ds_read_b32).
+// The N x N matrices are never materialised; per-workgroup partial sums / row sums /
+// gradient slabs are combined by mmd_finalize_kernel in a fixed order (no atomics).
+#include <mutex>
+
+#include "tvae_common.h"
+
+namespace tvae {
+namespace {
+
+constexpr int ROWS_PER_WG = 32;
+constexpr int TILE_P = 16;
+
+struct MmdArgs {
+    const float* cols[2];    // padded fp32 copies: [0] = z_all, [1] = y_all, row stride DPAD
+    const float* cnorm[2];   // squared norms (0 for padding rows)
+    int n_rows, n_cols, row_offset;
+    int row_blocks, col_splits, tiles_per_set, n_rows_pad;
+    float inv_d2;
+    double* wg_sums;         // [2 * row_blocks * col_splits][2]
+    double* wg_rowsum;       // [col_splits][n_rows_pad]
+    float* wg_grad;          // [col_splits][n_rows_pad][DPAD]
+};
+
+// expm1(-t) for t >= 0.  Below 1/8 a degree-6 Taylor polynomial (truncation < 1e-10);
+// otherwise the library expm1f.  The slow branch is skipped when no lane of the wave needs it.
+__device__ __forceinline__ float em1_neg(float t) {
+    const float x = -t;
+    float p = 1.f / 720.f;
+    p = fmaf(p, x, 1.f / 120.f);
+    p = fmaf(p, x, 1.f / 24.f);
+    p = fmaf(p, x, 1.f / 6.f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.f);
+    return p * x;
+}
+
+template <int NB, bool GRAD>
+__global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
+    constexpr int SW = 16 * NB;       // feature columns per wave
+    constexpr int LDS_LD = SW + 4;    // padded row stride of the staged tile (floats)
+    constexpr int DPAD = 64 * NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    float* xs = smem + wave * (TILE_P * LDS_LD);
+    f32x4* xch = reinterpret_cast<f32x4*>(smem + 4 * TILE_P * LDS_LD);
+
+    const int per_problem = a.row_blocks * a.col_splits;
+    const int bid = blockIdx.x;
+    const int problem = bid / per_problem;       // 0: rows = z (both column sets), 1: rows = y (y columns only)
+    const int rem = bid - problem * per_problem;
+    const int rb = rem / a.col_splits, sp = rem - rb * a.col_splits;
+    const int i0 = rb * ROWS_PER_WG;
+
+    // ---- the 32 rows of this workgroup: this wave's feature slice, kept in registers ----
+    const float* rows = a.cols[problem] + (long long)a.row_offset * DPAD;
+    const float* rnorm = a.cnorm[problem] + a.row_offset;
+    f32x4 zreg[2][NB];
+    float rn[2];
+    bool valid_i[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = i0 + 16 * t + i16;
+        valid_i[t] = row < a.n_rows;
+        const float* zp = rows + (long long)row * DPAD + wave * SW + 4 * g;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            if (valid_i[t]) zreg[t][m] = *reinterpret_cast<const f32x4*>(zp + 16 * m);
+            else zreg[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        rn[t] = valid_i[t] ? rnorm[row] : 0.f;
+    }
+
+    f32x4 acc[GRAD ? NB : 1][2];
+    if (GRAD) {
+#pragma unroll
+        for (int db = 0; db < NB; ++db) {
+            acc[db][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[db][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const bool do_grad = GRAD && problem == 0;
+
+    const long long tps = a.tiles_per_set;
+    const long long total = problem == 0 ? 2 * tps : tps;
+    const long long base = problem == 0 ? 0 : tps;
+    const int tb = (int)(base + sp * total / a.col_splits);
+    const int te = (int)(base + (sp + 1) * total / a.col_splits);
+
+    double sum0 = 0.0, sum1 = 0.0;     // per-lane partial of sum E over set 0 / set 1
+    double rowsum0 = 0.0, rowsum1 = 0.0;  // signed row sums R for the two 16-row groups
+
+    for (int tile = tb; tile < te; ++tile) {
+        const int set = tile >= tps ? 1 : 0;
+        const int p0 = (tile - set * (int)tps) * TILE_P;
+        const float* X = a.cols[set] + (long long)p0 * DPAD + wave * SW;
+
+        // 1. stage this wave's slice of the point tile (rows past n_cols are zero in the padded copy)
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = it * 64 + lane;
+            const int row = idx / (4 * NB), c4 = idx - row * (4 * NB);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (long long)row * DPAD + c4 * 4);
+            *reinterpret_cast<f32x4*>(xs + row * LDS_LD + c4 * 4) = v;
+        }
+
+        // 2. partial Gram over the slice: S'[p][i], p = point (A rows), i = our rows (B columns)
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(xs + i16 * LDS_LD + 16 * m + 4 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], zreg[0][m][q], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], zreg[1][m][q], s1, 0, 0, 0);
+            }
+        }
+
+        // 3. exchange the four slice partials (double-buffered: one barrier per tile)
+        const int buf = (tile - tb) & 1;
+        f32x4* xb = xch + buf * (4 * 2 * 64);
+        xb[(wave * 2 + 0) * 64 + lane] = s0;
+        xb[(wave * 2 + 1) * 64 + lane] = s1;
+        __syncthreads();
+        s0 = (xb[(0 * 2 + 0) * 64 + lane] + xb[(1 * 2 + 0) * 64 + lane]) +
+             (xb[(2 * 2 + 0) * 64 + lane] + xb[(3 * 2 + 0) * 64 + lane]);
+        s1 = (xb[(0 * 2 + 1) * 64 + lane] + xb[(1 * 2 + 1) * 64 + lane]) +
+             (xb[(2 * 2 + 1) * 64 + lane] + xb[(3 * 2 + 1) * 64 + lane]);
+
+        // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
+        const f32x4 cn = *reinterpret_cast<const f32x4*>(a.cnorm[set] + p0 + 4 * g);
+        f32x4 t0, t1, e0, e1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t0[r] = fmaxf((cn[r] + rn[0] - 2.f * s0[r]) * a.inv_d2, 0.f);
+            t1[r] = fmaxf((cn[r] + rn[1] - 2.f * s1[r]) * a.inv_d2, 0.f);
+            e0[r] = em1_neg(t0[r]);
+            e1[r] = em1_neg(t1[r]);
+        }
+        const float tmax = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])),
+                                 fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
+        if (__any(tmax >= 0.125f)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (t0[r] >= 0.125f) e0[r] = expm1f(-t0[r]);
+                if (t1[r] >= 0.125f) e1[r] = expm1f(-t1[r]);
+            }
+        }
+        if (!valid_i[0]) e0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!valid_i[1]) e1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p0 + TILE_P > a.n_cols) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (p0 + 4 * g + r >= a.n_cols) { e0[r] = 0.f; e1[r] = 0.f; }
+        }
+        const float es0 = (e0[0] + e0[1]) + (e0[2] + e0[3]);
+        const float es1 = (e1[0] + e1[1]) + (e1[2] + e1[3]);
+        if (set) {
+            sum1 += (double)(es0 + es1);
+            rowsum0 -= (double)es0;
+            rowsum1 -= (double)es1;
+        } else {
+            sum0 += (double)(es0 + es1);
+            rowsum0 += (double)es0;
+            rowsum1 += (double)es1;
+        }
+
+        // 5. gradient accumulation: acc^T[d][i] += sum_p X[p][d] * (s_p E'[p][i])
+        if (do_grad) {
+            if (set) { e0 = -e0; e1 = -e1; }
+#pragma unroll
+            for (int db = 0; db < NB; ++db) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float av = xs[(4 * g + r) * LDS_LD + 16 * db + i16];
+                    acc[db][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, e0[r], acc[db][0], 0, 0, 0);
+                    acc[db][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, e1[r], acc[db][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- per-workgroup results (every wave holds identical sums; wave 0 writes) ----
+    const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
+    if (tid == 0) {
+        a.wg_sums[2 * (long long)bid + 0] = w0;
+        a.wg_sums[2 * (long long)bid + 1] = w1;
+    }
+    if (do_grad) {
+        double r0v = rowsum0, r1v = rowsum1;
+        r0v += __shfl_xor(r0v, 16, 64); r0v += __shfl_xor(r0v, 32, 64);
+        r1v += __shfl_xor(r1v, 16, 64); r1v += __shfl_xor(r1v, 32, 64);
+        if (wave == 0 && g == 0) {
+            double* rs = a.wg_rowsum + (long long)sp * a.n_rows_pad + i0;
+            rs[i16] = r0v;
+            rs[16 + i16] = r1v;
+        }
+        // acc[db][t][reg] = G[row i0+16t+i16][d = wave*SW + 16 db + 4 g + reg]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* grow = a.wg_grad + ((long long)sp * a.n_rows_pad + i0 + 16 * t + i16) * DPAD + wave * SW + 4 * g;
+#pragma unroll
+            for (int db = 0; db < NB; ++db) *reinterpret_cast<f32x4*>(grow + 16 * db) = acc[GRAD ? db : 0][t];
+        }
+    }
+}
+
+// ---- prep: fp32 zero-padded copies (row stride DPAD), squared norms, per-wave column sums ----
+template <typename T>
+__global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, const T* __restrict__ y, int n_total,
+                                                       int n_pad, int D, int NB, float* __restrict__ zp,
+                                                       float* __restrict__ yp, float* __restrict__ zn,
+                                                       float* __restrict__ yn, float* __restrict__ colpart,
+                                                       int rows_per_wave, int nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wg >= nwaves) return;
+    const int set = blockIdx.y;
+    const T* __restrict__ src = set ? y : z;
+    float* __restrict__ dst = set ? yp : zp;
+    float* __restrict__ nrm = set ? yn : zn;
+    const int DPAD = 64 * NB;
+    float csum[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) csum[j] = 0.f;
+    const int r0 = wg * rows_per_wave;
+    const int r1 = min(n_pad, r0 + rows_per_wave);
+    for (int row = r0; row < r1; ++row) {
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < NB) {
+                const int c = lane + 64 * j;
+                const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
+                dst[(long long)row * DPAD + c] = v;
+                csum[j] += v;
+                sq = fmaf(v, v, sq);
+            }
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) nrm[row] = sq;
+    }
+    float* cp = colpart + ((long long)set * nwaves + wg) * DPAD;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < NB) cp[lane + 64 * j] = csum[j];
+}
+
+// shift[c] = sum_rows z[.,c] - sum_rows y[.,c]  (fp64 accumulate over the per-wave partials)
+__global__ __launch_bounds__(256) void mmd_shift_kernel(const float* __restrict__ colpart, int nwaves, int DPAD,
+                                                        float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= DPAD) return;
+    double s = 0.0;
+    for (int w = 0; w < nwaves; ++w)
+        s += (double)colpart[(long long)w * DPAD + c] - (double)colpart[((long long)nwaves + w) * DPAD + c];
+    shift[c] = (float)s;
+}
+
+struct FinalArgs {
+    const double* wg_sums; int nwg0;     // problem-0 workgroups come first, then as many problem-1 ones
+    const double* wg_rowsum; const float* wg_grad; const float* shift; const float* zp;
+    int col_splits, n_rows, n_rows_pad, row_offset, D, DPAD;
+    double* sums3; float* loss; double loss_scale; double grad_scale;
+    void* d_z;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        double zz = 0.0, zy = 0.0, yy = 0.0;
+        for (int w = tid; w < f.nwg0; w += 256) {
+            zz += f.wg_sums[2 * (long long)w + 0];
+            zy += f.wg_sums[2 * (long long)w + 1];
+            yy += f.wg_sums[2 * ((long long)f.nwg0 + w) + 1];
+        }
+        red[0][tid] = zz; red[1][tid] = zy; red[2][tid] = yy;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                red[0][tid] += red[0][tid + o];
+                red[1][tid] += red[1][tid + o];
+                red[2][tid] += red[2][tid + o];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            f.sums3[0] = red[0][0]; f.sums3[1] = red[1][0]; f.sums3[2] = red[2][0];
+            if (f.loss) *f.loss = (float)(f.loss_scale * (red[2][0] + red[0][0] - 2.0 * red[1][0]));
+        }
+    }
+    if (!f.d_z) return;
+    T* out = static_cast<T*>(f.d_z);
+    const long long total = (long long)f.n_rows * f.D;
+    for (long long idx = (long long)blockIdx.x * 256 + tid; idx < total; idx += (long long)gridDim.x * 256) {
+        const int row = (int)(idx / f.D), c = (int)(idx - (long long)row * f.D);
+        double rsum = 0.0;
+        float gsum = 0.f;
+        for (int s = 0; s < f.col_splits; ++s) {
+            rsum += f.wg_rowsum[(long long)s * f.n_rows_pad + row];
+            gsum += f.wg_grad[((long long)s * f.n_rows_pad + row) * f.DPAD + c];
+        }
+        const double zv = (double)f.zp[((long long)f.row_offset + row) * f.DPAD + c];
+        const double v = f.grad_scale * (-zv * rsum + (double)f.shift[c] + (double)gsum);
+        out[idx] = from_f32<T>((float)v);
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------
+struct Plan {
+    int NB, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
+    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_sums, off_rowsum, off_grad, bytes;
+};
+
+int pick_nb(int64_t D) {
+    static const int opts[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int nb : opts)
+        if (64 * nb >= D) return nb;
+    return 0;
+}
+
+bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan* p) {
+    p->NB = pick_nb(D);
+    if (p->NB == 0) return false;
+    p->DPAD = 64 * p->NB;
+    p->n_pad = (int)align_up(n_total, TILE_P);
+    p->row_blocks = (int)((n_rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
+    p->n_rows_pad = p->row_blocks * ROWS_PER_WG;
+    p->tiles_per_set = p->n_pad / TILE_P;
+    int cs = 1;
+    if (p->row_blocks < 512) cs = (512 + p->row_blocks - 1) / p->row_blocks;
+    const int max_cs = p->tiles_per_set >= 4 ? p->tiles_per_set / 4 : 1;
+    if (cs > max_cs) cs = max_cs;
+    if (cs > 64) cs = 64;
+    p->col_splits = cs < 1 ? 1 : cs;
+    int rpw = (p->n_pad + 2047) / 2048;
+    if (rpw < 4) rpw = 4;
+    if (rpw > 64) rpw = 64;
+    p->rows_per_wave = rpw;
+    p->nwaves = (p->n_pad + rpw - 1) / rpw;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
+    p->off_zp = take((int64_t)p->n_pad * p->DPAD * 4);
+    p->off_yp = take((int64_t)p->n_pad * p->DPAD * 4);
+    p->off_zn = take((int64_t)p->n_pad * 4);
+    p->off_yn = take((int64_t)p->n_pad * 4);
+    p->off_colpart = take((int64_t)2 * p->nwaves * p->DPAD * 4);
+    p->off_shift = take((int64_t)p->DPAD * 4);
+    p->off_sums = take((int64_t)2 * p->row_blocks * p->col_splits * 2 * 8);
+    p->off_rowsum = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * 8 : 0);
+    p->off_grad = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * p->DPAD * 4 : 0);
+    p->bytes = off;
+    return true;
+}
+
+template <int NB, bool GRAD>
+int launch_tile(const MmdArgs& a, int nblocks, hipStream_t s) {
+    constexpr int lds_bytes = (4 * TILE_P * (16 * NB + 4) + 2 * 4 * 2 * 64 * 4) * 4;
+    static std::once_flag once;
+    static hipError_t attr_status = hipSuccess;
+    std::call_once(once, [] {
+        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_tile_kernel<NB, GRAD>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    });
+    TVAE_CHECK_HIP(attr_status);
+    hipLaunchKernelGGL((mmd_tile_kernel<NB, GRAD>), dim3(nblocks), dim3(256), lds_bytes, s, a);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+template <bool GRAD>
+int launch_tile_nb(int NB, const MmdArgs& a, int nblocks, hipStream_t s) {
+    switch (NB) {
+        case 1: return launch_tile<1, GRAD>(a, nblocks, s);
+        case 2: return launch_tile<2, GRAD>(a, nblocks, s);
+        case 3: return launch_tile<3, GRAD>(a, nblocks, s);
+        case 4: return launch_tile<4, GRAD>(a, nblocks, s);
+        case 6: return launch_tile<6, GRAD>(a, nblocks, s);
+        case 8: return launch_tile<8, GRAD>(a, nblocks, s);
+        case 12: return launch_tile<12, GRAD>(a, nblocks, s);
+        case 16: return launch_tile<16, GRAD>(a, nblocks, s);
+    }
+    return fail(TVAE_ERR_ARG, "mmd: no kernel for NB=%d", NB);
+}
+
+}  // namespace
+}  // namespace tvae
+
+using namespace tvae;
+
+extern "C" int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad) {
+    Plan p;
+    if (n_total <= 0 || n_rows <= 0 || D <= 0 || !make_plan(n_total, n_rows, D, want_grad != 0, &p)) return -1;
+    return p.bytes;
+}
+
+extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
+                                int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
+                                double loss_scale, void* d_z, double grad_scale, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TVAE_REQUIRE(z_all && y_all && sums3 && workspace, "mmd: null pointer argument");
+    TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16, "mmd: unknown dtype %d", dtype);
+    TVAE_REQUIRE(n_total > 0 && n_rows > 0 && D > 0, "mmd: empty problem (n_total=%lld n_rows=%lld D=%lld)",
+                 (long long)n_total, (long long)n_rows, (long long)D);
+    TVAE_REQUIRE(row_offset >= 0 && row_offset + n_rows <= n_total, "mmd: row block [%lld,%lld) outside [0,%lld)",
+                 (long long)row_offset, (long long)(row_offset + n_rows), (long long)n_total);
+    TVAE_REQUIRE(n_total < (1ll << 30), "mmd: n_total too large");
+    Plan p;
+    TVAE_REQUIRE(make_plan(n_total, n_rows, D, d_z != nullptr, &p),
+                 "mmd: latent dimension %lld not supported (max 1024)", (long long)D);
+    if (workspace_bytes < p.bytes)
+        return fail(TVAE_ERR_WORKSPACE, "mmd: workspace %lld B < required %lld B", (long long)workspace_bytes,
+                    (long long)p.bytes);
+    TVAE_REQUIRE(aligned16(workspace), "mmd: workspace must be 16-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    float* zp = reinterpret_cast<float*>(ws + p.off_zp);
+    float* yp = reinterpret_cast<float*>(ws + p.off_yp);
+    float* zn = reinterpret_cast<float*>(ws + p.off_zn);
+    float* yn = reinterpret_cast<float*>(ws + p.off_yn);
+    float* colpart = reinterpret_cast<float*>(ws + p.off_colpart);
+    float* shift = reinterpret_cast<float*>(ws + p.off_shift);
+
+    dim3 pgrid((p.nwaves + 3) / 4, 2);
+    if (dtype == TVAE_F32)
+        hipLaunchKernelGGL(mmd_prep_kernel<float>, pgrid, dim3(256), 0, s, (const float*)z_all, (const float*)y_all,
+                           (int)n_total, p.n_pad, (int)D, p.NB, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
+    else
+        hipLaunchKernelGGL(mmd_prep_kernel<bf16>, pgrid, dim3(256), 0, s, (const bf16*)z_all, (const bf16*)y_all,
+                           (int)n_total, p.n_pad, (int)D, p.NB, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
+    TVAE_CHECK_HIP(hipGetLastError());
+    if (d_z) {
+        hipLaunchKernelGGL(mmd_shift_kernel, dim3((p.DPAD + 255) / 256), dim3(256), 0, s, colpart, p.nwaves, p.DPAD, shift);
+        TVAE_CHECK_HIP(hipGetLastError());
+    }
+
+    MmdArgs a;
+    a.cols[0] = zp; a.cols[1] = yp; a.cnorm[0] = zn; a.cnorm[1] = yn;
+    a.n_rows = (int)n_rows; a.n_cols = (int)n_total; a.row_offset = (int)row_offset;
+    a.row_blocks = p.row_blocks; a.col_splits = p.col_splits; a.tiles_per_set = p.tiles_per_set;
+    a.n_rows_pad = p.n_rows_pad;
+    a.inv_d2 = (float)(1.0 / ((double)D * (double)D));
+    a.wg_sums = reinterpret_cast<double*>(ws + p.off_sums);
+    a.wg_rowsum = reinterpret_cast<double*>(ws + p.off_rowsum);
+    a.wg_grad = reinterpret_cast<float*>(ws + p.off_grad);
+    const int nwg0 = p.row_blocks * p.col_splits;
+    if (d_z) TVAE_PROPAGATE(launch_tile_nb<true>(p.NB, a, 2 * nwg0, s));
+    else TVAE_PROPAGATE(launch_tile_nb<false>(p.NB, a, 2 * nwg0, s));
+
+    FinalArgs f;
+    f.wg_sums = a.wg_sums; f.nwg0 = nwg0; f.wg_rowsum = a.wg_rowsum; f.wg_grad = a.wg_grad; f.shift = shift; f.zp = zp;
+    f.col_splits = p.col_splits; f.n_rows = (int)n_rows; f.n_rows_pad = p.n_rows_pad; f.row_offset = (int)row_offset;
+    f.D = (int)D; f.DPAD = p.DPAD; f.sums3 = sums3; f.loss = loss; f.loss_scale = loss_scale; f.grad_scale = grad_scale;
+    f.d_z = d_z;
+    long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
+    if (fb > 4096) fb = 4096;
+    if (fb < 1) fb = 1;
+    if (dtype == TVAE_F32) hipLaunchKernelGGL(mmd_finalize_kernel<float>, dim3((unsigned)fb), dim3(256), 0, s, f);
+    else hipLaunchKernelGGL(mmd_finalize_kernel<bf16>, dim3((unsigned)fb), dim3(256), 0, s, f);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}

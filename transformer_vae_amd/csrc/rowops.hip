@@ -1,0 +1,243 @@
+// HBM-bound row/column passes around the projections: LayerNorm forward/backward,
+// tanh backward, deterministic column reductions (bias / gamma / beta gradients) and the
+// zero-fill of dh rows the latent slice never touched.  One wave (64 lanes) per row,
+// coalesced along the feature dimension, fp32 math on fp32 or bf16 storage.
+#include "tvae_common.h"
+
+namespace tvae {
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;     // one wave each
+constexpr int COL_CHUNK_ROWS = 128;   // rows summed per partial in the column reductions
+
+// ---- LayerNorm forward: autoencoders.py:64-67 (nn.LayerNorm(d, eps), biased variance) ----
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ r, const T* __restrict__ gamma,
+                                                     const T* __restrict__ beta, float eps, T* __restrict__ out,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     long long rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* x = r + row * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += to_f32(x[c]);
+    const float mu = wave_sum(s) / (float)d;
+    float v = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = to_f32(x[c]) - mu; v += t * t; }
+    const float rs = rsqrtf(wave_sum(v) / (float)d + eps);
+    T* o = out + row * d;
+    for (int c = lane; c < d; c += 64)
+        o[c] = from_f32<T>((to_f32(x[c]) - mu) * rs * to_f32(gamma[c]) + to_f32(beta[c]));
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// ---- LayerNorm backward, input gradient ----
+//   dxh = dout * gamma;  dr = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat))
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const T* __restrict__ dout, const T* __restrict__ r,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const T* __restrict__ gamma, T* __restrict__ dr,
+                                                          long long rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* g = dout + row * d;
+    const T* x = r + row * d;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float dxh = to_f32(g[c]) * to_f32(gamma[c]);
+        s1 += dxh;
+        s2 += dxh * ((to_f32(x[c]) - mu) * rs);
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+    T* o = dr + row * d;
+    for (int c = lane; c < d; c += 64) {
+        const float xh = (to_f32(x[c]) - mu) * rs;
+        o[c] = from_f32<T>(rs * (to_f32(g[c]) * to_f32(gamma[c]) - s1 - xh * s2));
+    }
+}
+
+// ---- column reductions: partial[chunk][c] over COL_CHUNK_ROWS rows, then a fixed-order sum ----
+// MODE 0: sum_r x[r][c];  MODE 1: (sum_r dout*xhat, sum_r dout) for LayerNorm gamma/beta.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ x, const T* __restrict__ r,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          long long rows, int cols, float* __restrict__ part0,
+                                                          float* __restrict__ part1) {
+    __shared__ float sm[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long rbeg = (long long)blockIdx.y * COL_CHUNK_ROWS;
+    const long long rend = min(rows, rbeg + (long long)COL_CHUNK_ROWS);
+    float a0 = 0.f, a1 = 0.f;
+    if (c < cols) {
+        for (long long row = rbeg + ry; row < rend; row += 4) {
+            const float v = to_f32(x[row * cols + c]);
+            if (MODE == 0) {
+                a0 += v;
+            } else {
+                a0 += v * ((to_f32(r[row * cols + c]) - mean[row]) * rstd[row]);
+                a1 += v;
+            }
+        }
+    }
+    sm[0][ry][cx] = a0;
+    sm[1][ry][cx] = a1;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        part0[(long long)blockIdx.y * cols + c] = (sm[0][0][cx] + sm[0][1][cx]) + (sm[0][2][cx] + sm[0][3][cx]);
+        if (MODE == 1)
+            part1[(long long)blockIdx.y * cols + c] = (sm[1][0][cx] + sm[1][1][cx]) + (sm[1][2][cx] + sm[1][3][cx]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict__ part, int chunks, int cols,
+                                                        T* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += (double)part[(long long)k * cols + c];
+    out[c] = from_f32<T>((float)s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                       T* __restrict__ dpre, long long count) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float zv = to_f32(z[i]);
+        dpre[i] = from_f32<T>(to_f32(dz[i]) * (1.f - zv * zv));
+    }
+}
+
+// dh[b, n_eff:S, :] = 0, 16 B per lane.  `tail` = (S - n_eff) * d elements per sequence.
+__global__ __launch_bounds__(256) void zero_tail_kernel(char* __restrict__ dh, long long seq_bytes, long long head_bytes,
+                                                        long long B) {
+    // grid.y walks sequences, grid.x * 256 threads stride over the tail of one sequence
+    const long long tail = seq_bytes - head_bytes;
+    for (long long b = blockIdx.y; b < B; b += gridDim.y) {
+        char* base = dh + b * seq_bytes + head_bytes;
+        // leading bytes up to 16-B alignment, then uint4 stores, then the remainder
+        const long long mis = (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
+        const long long lead = mis < tail ? mis : tail;
+        const long long nvec = (tail - lead) / 16;
+        const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (t0 < lead) base[t0] = 0;
+        uint4* v = reinterpret_cast<uint4*>(base + lead);
+        for (long long i = t0; i < nvec; i += (long long)gridDim.x * 256) v[i] = make_uint4(0, 0, 0, 0);
+        const long long done = lead + nvec * 16;
+        if (t0 < tail - done) base[done + t0] = 0;
+    }
+}
+
+inline int row_blocks(int64_t rows) { return (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+inline int col_chunks(int64_t rows) { return (int)((rows + COL_CHUNK_ROWS - 1) / COL_CHUNK_ROWS); }
+
+}  // namespace
+
+int layernorm_fwd(const void* r, const void* gamma, const void* beta, float eps, void* out, float* mean, float* rstd,
+                  int64_t rows, int64_t d, int dtype, hipStream_t s) {
+    if (rows == 0) return TVAE_OK;
+    if (dtype == TVAE_F32)
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(row_blocks(rows)), dim3(256), 0, s, (const float*)r,
+                           (const float*)gamma, (const float*)beta, eps, (float*)out, mean, rstd, (long long)rows, (int)d);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(row_blocks(rows)), dim3(256), 0, s, (const bf16*)r,
+                           (const bf16*)gamma, (const bf16*)beta, eps, (bf16*)out, mean, rstd, (long long)rows, (int)d);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+int layernorm_bwd_rows(const void* dout, const void* r, const float* mean, const float* rstd, const void* gamma,
+                       void* dr, int64_t rows, int64_t d, int dtype, hipStream_t s) {
+    if (rows == 0) return TVAE_OK;
+    if (dtype == TVAE_F32)
+        hipLaunchKernelGGL(ln_bwd_rows_kernel<float>, dim3(row_blocks(rows)), dim3(256), 0, s, (const float*)dout,
+                           (const float*)r, mean, rstd, (const float*)gamma, (float*)dr, (long long)rows, (int)d);
+    else
+        hipLaunchKernelGGL(ln_bwd_rows_kernel<bf16>, dim3(row_blocks(rows)), dim3(256), 0, s, (const bf16*)dout,
+                           (const bf16*)r, mean, rstd, (const bf16*)gamma, (bf16*)dr, (long long)rows, (int)d);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+int64_t colreduce_scratch_floats(int64_t rows, int64_t cols) { return (int64_t)col_chunks(rows) * cols; }
+
+int colsum(const void* x, int64_t rows, int64_t cols, void* out, int dtype, float* scratch, hipStream_t s) {
+    TVAE_REQUIRE(rows > 0 && cols > 0, "colsum: empty input");
+    const int chunks = col_chunks(rows);
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)chunks);
+    if (dtype == TVAE_F32) {
+        hipLaunchKernelGGL((col_partial_kernel<float, 0>), grid, dim3(256), 0, s, (const float*)x, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (long long)rows, (int)cols, scratch, (float*)nullptr);
+        hipLaunchKernelGGL(col_final_kernel<float>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, scratch, chunks,
+                           (int)cols, (float*)out);
+    } else {
+        hipLaunchKernelGGL((col_partial_kernel<bf16, 0>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (long long)rows, (int)cols, scratch, (float*)nullptr);
+        hipLaunchKernelGGL(col_final_kernel<bf16>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, scratch, chunks,
+                           (int)cols, (bf16*)out);
+    }
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+int layernorm_bwd_params(const void* dout, const void* r, const float* mean, const float* rstd, void* dgamma,
+                         void* dbeta, int64_t rows, int64_t d, int dtype, float* scratch, hipStream_t s) {
+    TVAE_REQUIRE(rows > 0 && d > 0, "layernorm_bwd_params: empty input");
+    const int chunks = col_chunks(rows);
+    float* p0 = scratch;
+    float* p1 = scratch + (int64_t)chunks * d;
+    dim3 grid((unsigned)((d + 63) / 64), (unsigned)chunks);
+    const dim3 fgrid((unsigned)((d + 255) / 256));
+    if (dtype == TVAE_F32) {
+        hipLaunchKernelGGL((col_partial_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)dout, (const float*)r, mean,
+                           rstd, (long long)rows, (int)d, p0, p1);
+        hipLaunchKernelGGL(col_final_kernel<float>, fgrid, dim3(256), 0, s, p0, chunks, (int)d, (float*)dgamma);
+        hipLaunchKernelGGL(col_final_kernel<float>, fgrid, dim3(256), 0, s, p1, chunks, (int)d, (float*)dbeta);
+    } else {
+        hipLaunchKernelGGL((col_partial_kernel<bf16, 1>), grid, dim3(256), 0, s, (const bf16*)dout, (const bf16*)r, mean,
+                           rstd, (long long)rows, (int)d, p0, p1);
+        hipLaunchKernelGGL(col_final_kernel<bf16>, fgrid, dim3(256), 0, s, p0, chunks, (int)d, (bf16*)dgamma);
+        hipLaunchKernelGGL(col_final_kernel<bf16>, fgrid, dim3(256), 0, s, p1, chunks, (int)d, (bf16*)dbeta);
+    }
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+int tanh_bwd(const void* dz, const void* z, void* dpre, int64_t count, int dtype, hipStream_t s) {
+    if (count == 0) return TVAE_OK;
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == TVAE_F32)
+        hipLaunchKernelGGL(tanh_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dz, (const float*)z,
+                           (float*)dpre, (long long)count);
+    else
+        hipLaunchKernelGGL(tanh_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)dz, (const bf16*)z,
+                           (bf16*)dpre, (long long)count);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype, hipStream_t s) {
+    if (S <= n_eff || B == 0) return TVAE_OK;
+    const int64_t esz = dtype == TVAE_F32 ? 4 : 2;
+    const long long seq_bytes = S * d * esz, head_bytes = n_eff * d * esz;
+    const long long tail_vec = (seq_bytes - head_bytes) / 16 + 1;
+    // enough workgroups to fill the chip: x over one sequence's tail, y over sequences
+    int gx = (int)((tail_vec + 255) / 256);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    int gy = (int)B;
+    const int want = 4096 / gx;
+    if (gy > want) gy = want;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(gx, gy), dim3(256), 0, s, (char*)dh, seq_bytes, head_bytes, (long long)B);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+}  // namespace tvae

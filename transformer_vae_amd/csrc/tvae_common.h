@@ -1,0 +1,125 @@
+// Shared helpers for libtvae_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/tvae_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace tvae {
+
+typedef __hip_bfloat16 bf16;
+
+// ---- error plumbing (thread-local message, int status) -------------------------------
+std::string& last_error_ref();
+int fail(int code, const char* fmt, ...);
+
+#define TVAE_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return ::tvae::fail(TVAE_ERR_HIP, "%s failed: %s (%s:%d)", #expr,             \
+                                hipGetErrorString(_e), __FILE__, __LINE__);               \
+    } while (0)
+
+#define TVAE_REQUIRE(cond, ...)                                                           \
+    do {                                                                                  \
+        if (!(cond)) return ::tvae::fail(TVAE_ERR_ARG, __VA_ARGS__);                      \
+    } while (0)
+
+#define TVAE_PROPAGATE(expr)                                                              \
+    do {                                                                                  \
+        int _s = (expr);                                                                  \
+        if (_s != TVAE_OK) return _s;                                                     \
+    } while (0)
+
+// ---- element access: fp32 math on fp32 / bf16 storage ---------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return __float2bfloat16(v); }
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t u16) { return __uint_as_float(u16 << 16); }
+
+// 4 consecutive elements -> fp32, vectorised (16 B fp32 / 8 B bf16); caller guarantees alignment.
+__device__ __forceinline__ void load4_vec(const float* p, float out[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+__device__ __forceinline__ void load4_vec(const bf16* p, float out[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    out[0] = bf16_bits_to_f32(v.x & 0xffffu); out[1] = bf16_bits_to_f32(v.x >> 16);
+    out[2] = bf16_bits_to_f32(v.y & 0xffffu); out[3] = bf16_bits_to_f32(v.y >> 16);
+}
+// Guarded form: element e is read only when e < nvalid (others are 0).
+template <typename T>
+__device__ __forceinline__ void load4_guard(const T* p, int nvalid, float out[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = (e < nvalid) ? to_f32(p[e]) : 0.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- row address maps -----------------------------------------------------------------
+// offset(r) = (r / grp) * so + (r % grp) * si   in elements.  A dense (rows, ld) matrix is
+// {grp = 1, so = ld, si = 0}; the first n tokens of every sequence of a (B,S,d) tensor are
+// {grp = n, so = stride_b, si = stride_s}.
+struct RowMap {
+    long long so, si;
+    int grp;
+    __host__ __device__ __forceinline__ long long operator()(int r) const {
+        return grp == 1 ? (long long)r * so : (long long)(r / grp) * so + (long long)(r % grp) * si;
+    }
+    bool vec_ok() const { return (so % 4 == 0) && (grp == 1 || si % 4 == 0); }
+};
+inline RowMap dense_rows(long long ld) { return RowMap{ld, 0, 1}; }
+
+// ---- internal launchers (one translation unit each) -----------------------------------
+enum Epilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_TANH = 2 };
+
+struct GemmDesc {
+    // C[m][n] = sum_k A(m,k) * B(k,n)  (+ bias[n], tanh)
+    const void* A; const void* B; void* C; const void* bias;
+    int M, N, K;
+    bool a_kmajor;   // false: A(m,k) = A[amap(m) + k];  true: A(m,k) = A[amap(k) + m]
+    bool b_kmajor;   // false: B(k,n) = B[bmap(n) + k];  true: B(k,n) = B[bmap(k) + n]
+    RowMap amap, bmap, cmap;   // cmap: C(m,n) = C[cmap(m) + n]
+    int epilogue;
+    int dtype;
+    float* slab; int64_t slab_floats;   // split-K scratch (fp32), may be null => no split
+};
+int64_t gemm_slab_floats(int M, int N, int K);
+int gemm_launch(const GemmDesc& g, hipStream_t stream);
+
+// row-wise / column-wise helpers (rowops.hip)
+int layernorm_fwd(const void* r, const void* gamma, const void* beta, float eps, void* out,
+                  float* mean, float* rstd, int64_t rows, int64_t d, int dtype, hipStream_t s);
+int layernorm_bwd_rows(const void* dout, const void* r, const float* mean, const float* rstd,
+                       const void* gamma, void* dr, int64_t rows, int64_t d, int dtype, hipStream_t s);
+// column reductions; scratch = colreduce_scratch_floats(rows, cols) fp32
+int64_t colreduce_scratch_floats(int64_t rows, int64_t cols);
+int colsum(const void* x, int64_t rows, int64_t cols, void* out, int dtype, float* scratch, hipStream_t s);
+int layernorm_bwd_params(const void* dout, const void* r, const float* mean, const float* rstd,
+                         void* dgamma, void* dbeta, int64_t rows, int64_t d, int dtype,
+                         float* scratch /* 2x colreduce_scratch_floats */, hipStream_t s);
+int tanh_bwd(const void* dz, const void* z, void* dpre, int64_t count, int dtype, hipStream_t s);
+int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype, hipStream_t s);
+
+}  // namespace tvae

@@ -1,0 +1,63 @@
+"""Global-batch MMD, row-sharded over a process group (one process per GPU, RCCL over xGMI).
+
+The reference has no collective of its own: under DDP every rank computes the MMD of its
+LOCAL batch.  That behaviour is ``mmd_scope="local"`` and needs nothing
+from this file.  ``mmd_scope="global"`` evaluates the MMD of the concatenated batch:
+
+  1. all-gather the (N/R, D) latent and prior row blocks          -> (N, D) on every rank
+  2. each rank evaluates ITS row block of Kzz / Kzy / Kyy against all N columns and the
+     COMPLETE gradient of its own rows (no gradient exchange: SURVEY.md 8e)
+  3. all-reduce three fp64 partial sums                            -> identical loss everywhere
+
+The compute of step 2 is injected (``row_block_fn``) so that the collective logic can be
+exercised on CPU with gloo by the tests; the package default is the HIP kernel and nothing
+else.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import functional as F
+
+
+def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate equally sized row blocks from every rank, in rank order."""
+    world = dist.get_world_size(group)
+    x = x.contiguous()
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    try:
+        dist.all_gather_into_tensor(out, x, group=group)
+    except (RuntimeError, NotImplementedError):
+        dist.all_gather(list(out.chunk(world, dim=0)), x, group=group)
+    return out
+
+
+def sharded_mmd_reg_loss(latent2d: torch.Tensor, prior_local: torch.Tensor, batch_size_local: int, n_latents: int,
+                         group=None, compensate_ddp_mean: bool = False,
+                         row_block_fn: Optional[Callable] = None) -> torch.Tensor:
+    """reg_loss of the GLOBAL batch; every rank returns the same value.
+
+    latent2d / prior_local: this rank's (N/R, D) rows (equal counts on all ranks).
+    The gradient that flows into ``latent2d`` is d(global reg)/d(local rows), complete.
+    ``compensate_ddp_mean``: DDP averages parameter gradients over R ranks while each rank
+    holds only its rows' share of the global loss gradient; multiplying the local gradient
+    by R makes the averaged result equal the single-process global-batch gradient."""
+    fn = row_block_fn or F.mmd_row_block
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local, dim = latent2d.shape
+    z_all = all_gather_rows(latent2d.detach(), group)
+    y_all = all_gather_rows(prior_local, group)
+    n_total = n_local * world
+    loss_scale, grad_scale = F.mmd_scales(batch_size_local * world, n_latents, n_total, dim)
+    if compensate_ddp_mean:
+        grad_scale *= world
+    local, sums = fn(latent2d, z_all, y_all, rank * n_local, loss_scale, grad_scale)
+    sums = sums.detach().clone()
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    reg = ((sums[2] + sums[0] - 2.0 * sums[1]) * loss_scale).to(torch.float32)
+    # value: the global loss; gradient: through this rank's row block only
+    return reg.detach() + (local - local.detach())

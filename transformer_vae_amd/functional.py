@@ -1,0 +1,235 @@
+"""torch.autograd.Functions over the C ABI (include/tvae_hip.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream and autograd's graph.
+Every number is produced by the hand-written kernels in csrc/.  Inputs must live on a
+ROCm device; anything else raises (no CPU path).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.TVAE_F32, torch.bfloat16: _lib.TVAE_BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
+    if nbytes < 0:
+        raise RuntimeError("libtvae_hip: unsupported problem size (workspace query failed)")
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the bottleneck kernels run on MI355X only "
+                           "(there is no CPU fallback)")
+
+
+def _compute_dtype(t: torch.Tensor) -> torch.dtype:
+    """fp32 stays fp32; bf16 (or an active bf16 autocast region) computes on bf16 storage."""
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return torch.bfloat16
+    return torch.bfloat16 if t.dtype == torch.bfloat16 else torch.float32
+
+
+class _LatentEncode(torch.autograd.Function):
+    """latent = tanh(h[:, :n] @ We^T + be)      (reference: autoencoders.py:21-22)."""
+
+    @staticmethod
+    def forward(ctx, h, We, be, n_tokens: int):
+        _require_device(h, "latent encoder")
+        if h.dim() != 3:
+            raise ValueError(f"encoder input must be (batch, seq, d_model), got {tuple(h.shape)}")
+        out_dtype = h.dtype
+        dt = _compute_dtype(h)
+        hc = h.to(dt)
+        if hc.stride(2) != 1:
+            hc = hc.contiguous()
+        Wc, bc = We.to(dt).contiguous(), be.to(dt).contiguous()
+        B, S, d = hc.shape
+        L = Wc.shape[0]
+        if Wc.shape[1] != d:
+            raise ValueError(f"token_to_latent expects d_model={Wc.shape[1]}, got hidden size {d}")
+        n_eff = min(int(n_tokens), S)          # the reference's slice silently truncates (:22)
+        z = torch.empty((B, n_eff, L), dtype=dt, device=h.device)
+        if B * n_eff > 0:
+            lib = _lib.lib()
+            ws = _workspace(lib.tvae_encode_fwd_workspace_bytes(B, n_eff, d, L), h.device)
+            _lib.check(lib.tvae_encode_fwd(_ptr(hc), hc.stride(0), hc.stride(1), _ptr(Wc), _ptr(bc), _ptr(z),
+                                           B, n_eff, d, L, _DTYPES[dt], _ptr(ws), ws.numel(), _stream(hc)),
+                       "tvae_encode_fwd")
+        ctx.save_for_backward(hc, Wc, z)
+        ctx.meta = (B, S, d, L, n_eff, dt, h.dtype, We.dtype, be.dtype)
+        return z if dt == out_dtype or torch.is_autocast_enabled() else z.to(out_dtype)
+
+    @staticmethod
+    def backward(ctx, dz):
+        hc, Wc, z = ctx.saved_tensors
+        B, S, d, L, n_eff, dt, h_dtype, w_dtype, b_dtype = ctx.meta
+        need_h, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dzc = dz.to(dt).contiguous()
+        dh = torch.empty((B, S, d), dtype=dt, device=hc.device) if need_h else None
+        dWe = torch.empty((L, d), dtype=dt, device=hc.device) if need_w else None
+        dbe = torch.empty((L,), dtype=dt, device=hc.device) if need_b else None
+        if B * n_eff == 0:
+            for t in (dh, dWe, dbe):
+                if t is not None:
+                    t.zero_()
+        else:
+            lib = _lib.lib()
+            ws = _workspace(lib.tvae_encode_bwd_workspace_bytes(B, n_eff, d, L), hc.device)
+            _lib.check(lib.tvae_encode_bwd(_ptr(dzc), _ptr(z), _ptr(hc), hc.stride(0), hc.stride(1), _ptr(Wc),
+                                           _ptr(dh), _ptr(dWe), _ptr(dbe), B, S, n_eff, d, L, _DTYPES[dt],
+                                           _ptr(ws), ws.numel(), _stream(hc)), "tvae_encode_bwd")
+        cast = lambda t, to: None if t is None else (t if t.dtype == to else t.to(to))
+        return cast(dh, h_dtype), cast(dWe, w_dtype), cast(dbe, b_dtype), None
+
+
+class _LatentDecode(torch.autograd.Function):
+    """recon = [LayerNorm]( latent @ Wd^T + bd )    (reference: autoencoders.py:38-39, 66-67)."""
+
+    @staticmethod
+    def forward(ctx, z, Wd, bd, gamma, beta, eps: float):
+        _require_device(z, "latent decoder")
+        out_dtype = z.dtype
+        dt = _compute_dtype(z)
+        lead = z.shape[:-1]
+        L = z.shape[-1]
+        zc = z.to(dt).reshape(-1, L).contiguous()
+        N = zc.shape[0]
+        has_lin, has_ln = Wd is not None, gamma is not None
+        d = Wd.shape[0] if has_lin else L
+        if has_lin and Wd.shape[1] != L:
+            raise ValueError(f"latent_to_token expects latent_size={Wd.shape[1]}, got {L}")
+        Wc = Wd.to(dt).contiguous() if has_lin else None
+        bc = bd.to(dt).contiguous() if has_lin else None
+        gc = gamma.to(dt).contiguous() if has_ln else None
+        btc = beta.to(dt).contiguous() if has_ln else None
+        dev = z.device
+        recon = torch.empty((N, d), dtype=dt, device=dev)
+        pre = torch.empty((N, d), dtype=dt, device=dev) if (has_lin and has_ln) else None
+        mean = torch.empty((N,), dtype=torch.float32, device=dev) if has_ln else None
+        rstd = torch.empty((N,), dtype=torch.float32, device=dev) if has_ln else None
+        if N > 0:
+            lib = _lib.lib()
+            ws = _workspace(lib.tvae_decode_fwd_workspace_bytes(N, L, d), dev)
+            _lib.check(lib.tvae_decode_fwd(_ptr(zc), _ptr(Wc), _ptr(bc), _ptr(gc), _ptr(btc), float(eps), _ptr(recon),
+                                           _ptr(pre), _ptr(mean), _ptr(rstd), N, L, d, _DTYPES[dt], _ptr(ws),
+                                           ws.numel(), _stream(zc)), "tvae_decode_fwd")
+        ctx.save_for_backward(zc, Wc, gc, pre, mean, rstd)
+        ctx.meta = (N, L, d, dt, tuple(lead), z.dtype,
+                    None if Wd is None else Wd.dtype, None if gamma is None else gamma.dtype)
+        out = recon.reshape(*lead, d)
+        return out if dt == out_dtype or torch.is_autocast_enabled() else out.to(out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        zc, Wc, gc, pre, mean, rstd = ctx.saved_tensors
+        N, L, d, dt, lead, z_dtype, w_dtype, g_dtype = ctx.meta
+        need = ctx.needs_input_grad
+        dev = zc.device
+        dc = dout.to(dt).reshape(N, d).contiguous()
+        has_lin, has_ln = Wc is not None, gc is not None
+        dz = torch.empty((N, L), dtype=dt, device=dev) if need[0] else None
+        dWd = torch.empty((d, L), dtype=dt, device=dev) if (has_lin and need[1]) else None
+        dbd = torch.empty((d,), dtype=dt, device=dev) if (has_lin and need[2]) else None
+        want_ln = has_ln and (need[3] or need[4])
+        dgamma = torch.empty((d,), dtype=dt, device=dev) if want_ln else None
+        dbeta = torch.empty((d,), dtype=dt, device=dev) if want_ln else None
+        if N == 0:
+            for t in (dWd, dbd, dgamma, dbeta):
+                if t is not None:
+                    t.zero_()
+        else:
+            lib = _lib.lib()
+            ws = _workspace(lib.tvae_decode_bwd_workspace_bytes(N, L, d), dev)
+            _lib.check(lib.tvae_decode_bwd(_ptr(dc), _ptr(zc), _ptr(Wc), _ptr(gc), _ptr(pre), _ptr(mean), _ptr(rstd),
+                                           _ptr(dz), _ptr(dWd), _ptr(dbd), _ptr(dgamma), _ptr(dbeta), N, L, d,
+                                           _DTYPES[dt], _ptr(ws), ws.numel(), _stream(zc)), "tvae_decode_bwd")
+        cast = lambda t, to: None if t is None else (t if t.dtype == to else t.to(to))
+        dz_out = None if dz is None else cast(dz.reshape(*lead, L), z_dtype)
+        return dz_out, cast(dWd, w_dtype), cast(dbd, w_dtype), cast(dgamma, g_dtype), cast(dbeta, g_dtype), None
+
+
+class _MMDRegulariser(torch.autograd.Function):
+    """reg = MMD(prior, latent) * scale, forward and gradient in one device pass
+    (reference: autoencoders.py:117-136; closed-form gradient SURVEY.md 8a).
+
+    ``row_offset``/``z_all``/``y_all`` implement the row-sharded global-batch form: the
+    caller has already all-gathered latents and priors; this rank evaluates its row block
+    and returns the three partial sums, which the caller all-reduces."""
+
+    @staticmethod
+    def forward(ctx, z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float):
+        _require_device(z_all, "MMD regulariser")
+        dt = torch.bfloat16 if (z_all.dtype == torch.bfloat16 and y_all.dtype == torch.bfloat16) else torch.float32
+        za = z_all.detach().to(dt).contiguous()
+        ya = y_all.detach().to(dt).contiguous()
+        n_total, D = za.shape
+        if tuple(ya.shape) != (n_total, D):
+            raise ValueError(f"prior samples {tuple(ya.shape)} must match latents {(n_total, D)}")
+        n_rows = z_rows.shape[0]
+        want_grad = bool(ctx.needs_input_grad[0])
+        dev = za.device
+        lib = _lib.lib()
+        ws = _workspace(lib.tvae_mmd_workspace_bytes(n_total, n_rows, D, int(want_grad)), dev)
+        sums = torch.empty(3, dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dz = torch.empty((n_rows, D), dtype=dt, device=dev) if want_grad else None
+        _lib.check(lib.tvae_mmd_fwd_bwd(_ptr(za), _ptr(ya), n_total, int(row_offset), n_rows, D, _DTYPES[dt],
+                                        _ptr(sums), _ptr(loss), float(loss_scale), _ptr(dz), float(grad_scale),
+                                        _ptr(ws), ws.numel(), _stream(za)), "tvae_mmd_fwd_bwd")
+        if want_grad:
+            ctx.save_for_backward(dz)
+        ctx.z_dtype = z_rows.dtype
+        ctx.mark_non_differentiable(sums)
+        return loss, sums
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_sums):
+        (dz,) = ctx.saved_tensors
+        g = (dz.float() * g_loss.float()).to(ctx.z_dtype)
+        return g, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------
+# functional API used by the modules in autoencoders.py
+# ------------------------------------------------------------------------------------------
+
+def latent_encode(h, weight, bias, n_tokens: int):
+    return _LatentEncode.apply(h, weight, bias, int(n_tokens))
+
+
+def latent_decode(z, weight=None, bias=None, ln_weight=None, ln_bias=None, eps: float = 1e-5):
+    return _LatentDecode.apply(z, weight, bias, ln_weight, ln_bias, float(eps))
+
+
+def mmd_scales(batch_size: int, n_latents: int, n_total: int, dim: int):
+    """(loss_scale, grad_scale) for reg = MMD / batch * n_latents (autoencoders.py:112):
+    reg = loss_scale * (S_yy + S_zz - 2 S_zy),  d reg/d z = grad_scale * [...]."""
+    loss_scale = n_latents / (batch_size * float(n_total) ** 2)
+    grad_scale = 4.0 * n_latents / (batch_size * float(n_total) ** 2 * float(dim) ** 2)
+    return loss_scale, grad_scale
+
+
+def mmd_reg_loss(latent2d, prior, batch_size: int, n_latents: int):
+    """Single-device regulariser: MMD(prior, latent) / batch_size * n_latents, fp32 scalar."""
+    n_total, dim = latent2d.shape
+    ls, gs = mmd_scales(batch_size, n_latents, n_total, dim)
+    loss, _ = _MMDRegulariser.apply(latent2d, latent2d, prior, 0, ls, gs)
+    return loss
+
+
+def mmd_row_block(z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float):
+    """Row-sharded building block: returns (local loss share, float64[3] partial sums)."""
+    return _MMDRegulariser.apply(z_rows, z_all, y_all, int(row_offset), float(loss_scale), float(grad_scale))
