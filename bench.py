@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py — bottleneck+MMD forward+backward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4] [--dtype fp32]
+
+A step = one pass of the hot path over one batch of synthetic hidden states:
+    out  = vae(h, true_samples=prior)                        (encode -> MMD -> decode)
+    loss = out.reg_loss * 0.5 + <out.reconstructed_encoding, G0>
+    loss.backward()                                          (grads for h and every parameter)
+Default workload: BASELINE.json configs[3] — large_model (d_model 1024) full_30_tkn, GLOBAL batch
+8192 (N = 245 760 latent rows, D = 768), the configuration the metric's 1/2/4/8-GPU and
+%-of-MFMA-roofline figures are quoted on; it fits one GPU, so N=1 runs the whole global batch and
+N>1 row-shards the same batch (strong scaling: all-gather of latents + 3-double all-reduce).
+Rank 0 prints ONE JSON line.  See DESIGN.md section "Measurement".
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# name: (B_global, S, d, n, L, cfg_id, BASELINE.json configs[] label)
+CONFIGS = {
+    "cfg1": (8, 60, 512, 5, 77, 1, "configs[0] t5-small mnist_small+tenth_5_tkn batch 8"),
+    "cfg2": (70, 30, 768, 5, 77, 2, "configs[1] syntax t5-base 30Seq 5 latent tokens batch_large"),
+    "cfg3": (1024, 237, 768, 5, 77, 3, "configs[2] mnist_base funnel_small window200 237-seq batch 1024"),
+    "cfg4": (8192, 30, 1024, 30, 768, 4, "configs[3] large_model d_model 1024 full_30_tkn global batch 8192"),
+    "cfg5": (65536, 1, 1024, 1, 1024, 5, "configs[4] MMD stress global batch 65536 latent dim 1024"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= vector fp32 peak)
+REG_W = 0.5
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class HipEvents:
+    """Raw hipEvent_t pairs (ctypes on libamdhip64) handed to tvae_profile_next_mmd."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.pairs = []
+
+    def new_pair(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
+        self.pairs.append((a, b))
+        return a, b
+
+    def durations_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = ctypes.c_float()
+            if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0:
+                out.append(ms.value)
+        return out
+
+
+def make_vae(d, L, n, device, dtype, scope, world):
+    import transformer_vae_amd as amd
+    cfg = SimpleNamespace(t5=SimpleNamespace(d_model=d), funnel=SimpleNamespace(d_model=d, layer_norm_eps=1e-9),
+                          latent_size=L, n_latent_tokens=n)
+    torch.manual_seed(0)      # default nn.Linear / LayerNorm init under seed 0
+    vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](cfg), amd.VAE_DECODER_MODELS[""](cfg), True,
+                                mmd_scope=scope, compensate_ddp_mean=False)
+    return vae.to(device).to(dtype)
+
+
+def cpu_baseline(cfg_name, world):
+    """The oracle (a CPU port of the reference arithmetic) timed on this host, on a bounded sample.
+
+    cfg1/cfg2: the literal op sequence of the reference (tile/sub/square/mean/exp, autograd) on the
+    whole batch.  cfg3-5: the literal form cannot allocate its (N,N,D) temporaries, so the Gram-form
+    restatement is timed on a sample of latent rows against ALL N columns and scaled by N/rows."""
+    from oracle import bottleneck_oracle as orc
+    from oracle import literal_torch as lit
+    B, S, d, n, L, cfg_id, _ = CONFIGS[cfg_name]
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    n_eff = min(n, S)
+    N = B * n_eff
+    if cfg_name in ("cfg1", "cfg2"):
+        h, p, prior, g0 = orc.synth_inputs(B, S, d, n, L, cfg_id, "")
+        pt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in p.items()}
+        ht = torch.from_numpy(h).requires_grad_(True)
+        pr, g0t = torch.from_numpy(prior), torch.from_numpy(g0)
+        for _ in range(2):
+            lit.step_literal(ht, pt, n, pr, g0t, REG_W)
+        ts = []
+        t_end = time.perf_counter() + 15.0
+        while len(ts) < 20 and time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            lit.step_literal(ht, pt, n, pr, g0t, REG_W)
+            ts.append(time.perf_counter() - t0)
+        sec = float(np.median(ts))
+        return {"value": B / sec, "unit": "samples/s", "cores": threads, "kind": "port",
+                "sample": f"literal reference op sequence (oracle/literal_torch.py), whole batch B={B}, "
+                          f"median of {len(ts)} steps, torch CPU fp32"}
+    # Gram-form restatement, row sample
+    rows = 256 if N > 100_000 else 512
+    rs = np.random.RandomState(4321 + cfg_id)
+    z_all = np.tanh(rs.standard_normal((N, L))).astype(np.float32)
+    y_all = rs.standard_normal((N, L)).astype(np.float32)
+    t0 = time.perf_counter()
+    orc.mmd_partial_sums(z_all[:rows], y_all[:rows], z_all, y_all, chunk=rows)
+    orc.mmd_grad_latent_rows(z_all[:rows], z_all, y_all, chunk=rows)
+    t_mmd = (time.perf_counter() - t0) * (N / rows)
+    # projections on the same row sample (slice-first restatement), fwd + analytic bwd
+    bs = max(1, rows // n_eff)
+    h, p, prior, g0 = orc.synth_inputs(bs, min(S, n_eff), d, n, L, cfg_id, "")
+    t0 = time.perf_counter()
+    fwd = orc.bottleneck_forward(h, p, n, None, use_reg_loss=False)
+    orc.bottleneck_backward(h, p, n, fwd, g0)
+    t_proj = (time.perf_counter() - t0) * (B / bs)
+    sec = t_mmd + t_proj
+    return {"value": B / sec, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"Gram-form restatement (oracle/bottleneck_oracle.py, numpy fp32; the literal reference needs "
+                      f"{N * N * L * 4 / 2**30:.0f} GiB per temporary): {rows} of {N} latent rows against all {N} columns "
+                      f"(sums + gradient) and {bs} of {B} sequences through the projections, scaled to the full step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    B, S, d, n, L, cfg_id, label = CONFIGS[args.config]
+    if B % world:
+        raise SystemExit(f"global batch {B} not divisible by {world} ranks")
+    dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+    Bl = B // world
+    n_eff = min(n, S)
+    N, Nl = B * n_eff, Bl * n_eff
+
+    from transformer_vae_amd import _lib
+    lib = _lib.lib()
+    vae = make_vae(d, L, n, device, dtype, "global" if world > 1 else "local", world)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + cfg_id + 1000 * rank)
+    h = torch.randn((Bl, S, d), generator=gen, device=device, dtype=torch.float32).to(dtype).requires_grad_(True)
+    gen.manual_seed(4321 + cfg_id + 1000 * rank)
+    prior = torch.randn((Nl, L), generator=gen, device=device, dtype=torch.float32)
+    gen.manual_seed(99 + 1000 * rank)
+    g0 = (torch.randn((Bl, n_eff, d), generator=gen, device=device, dtype=torch.float32) / (N * d) ** 0.5).to(dtype)
+    params = list(vae.parameters())
+
+    events = HipEvents()
+
+    def step(timed):
+        h.grad = None
+        for p in params:
+            p.grad = None
+        if timed:
+            a, b = events.new_pair()
+            lib.tvae_profile_next_mmd(a, b)
+        out = vae(input_encoding=h, true_samples=prior)
+        loss = out.reg_loss * REG_W + (out.reconstructed_encoding * g0).sum()
+        loss.backward()
+        return out
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    reg = float(out.reg_loss)
+    assert np.isfinite(reg) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    assert h.grad is not None and h.grad.shape == h.shape
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (mmd_tile_kernel), measured live with HIP events ----
+    tile_ms = events.durations_ms()
+    kern_ms = float(np.mean(tile_ms)) if tile_ms else float("nan")
+    # algorithmic flops of one launch on this rank: 10 * N_local_rows * N * D (3 Grams fwd
+    # 6 N^2 D + 2 gradient products 4 N^2 D, no symmetry credit, recompute not counted)
+    flops = 10.0 * Nl * N * L
+    achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms == kern_ms else None
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"{args.config}_{args.dtype}_gpus{world}")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+                "kernel": "mmd_tile_kernel", "kernel_ms": kern_ms, "launches_timed": len(tile_ms),
+                "peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak; the Gram and gradient products run in exact fp32"}
+
+    line = {
+        "metric": "bottleneck+MMD fwd+bwd samples/sec", "value": value, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {label}", "global_batch": B, "seq_len": S, "d_model": d,
+                   "n_latent_tokens": n, "latent_size": L, "mmd_rows": N,
+                   "parallelism": f"row-sharded global-batch MMD x{world}" if world > 1 else "single GPU"},
+        "reg_loss": reg, "roofline": roofline,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.config, world)
+            except Exception as e:      # the baseline must never take the bench line down
+                line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -131,6 +131,12 @@ int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all,
                      void* d_z, double grad_scale,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Measurement hook — no counterpart in the reference.  Arms the NEXT tvae_mmd_fwd_bwd call made
+ * on this host thread: hipEventRecord(ev_start) / (ev_stop) are enqueued on that call's stream
+ * immediately before / after the dominant kernel (mmd_tile_kernel), so bench.py can time that
+ * kernel live with HIP events.  One-shot; pass NULLs to disarm.  Events are hipEvent_t as void*. */
+int tvae_profile_next_mmd(void* ev_start, void* ev_stop);
+
 #ifdef __cplusplus
 }
 #endif

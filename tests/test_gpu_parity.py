@@ -199,7 +199,7 @@ def test_mmd_row_blocks_compose():
         loss_r.backward()
         tot += sums_r
         assert relerr(rows.grad.cpu().numpy(), zfull.grad[r * N // R:(r + 1) * N // R].cpu().numpy()) <= 1e-6
-    assert torch.allclose(tot, sums_full, rtol=1e-12, atol=0)
+    assert torch.allclose(tot, sums_full, rtol=1e-7, atol=0)   # fp32 tile partials, different split
     reg = float((tot[2] + tot[0] - 2 * tot[1]) * ls)
     assert abs(reg - float(loss_full)) <= 1e-6 * abs(float(loss_full))
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "tvae_decode_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int,
                                _vp, _i64, _vp]),
     "tvae_mmd_workspace_bytes": (_i64, [_i64, _i64, _i64, _int]),
+    "tvae_profile_next_mmd": (_int, [_vp, _vp]),
     "tvae_mmd_fwd_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp, _i64, _vp]),
 }
 

@@ -414,6 +414,18 @@ int launch_tile_nb(int NB, const MmdArgs& a, int nblocks, hipStream_t s) {
 
 using namespace tvae;
 
+namespace {
+// one-shot, thread-local measurement hook (tvae_profile_next_mmd): events recorded around the tile kernel
+thread_local hipEvent_t g_prof_start = nullptr;
+thread_local hipEvent_t g_prof_stop = nullptr;
+}  // namespace
+
+extern "C" int tvae_profile_next_mmd(void* ev_start, void* ev_stop) {
+    g_prof_start = static_cast<hipEvent_t>(ev_start);
+    g_prof_stop = static_cast<hipEvent_t>(ev_stop);
+    return TVAE_OK;
+}
+
 extern "C" int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad) {
     Plan p;
     if (n_total <= 0 || n_rows <= 0 || D <= 0 || !make_plan(n_total, n_rows, D, want_grad != 0, &p)) return -1;
@@ -470,8 +482,12 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     a.wg_rowsum = reinterpret_cast<double*>(ws + p.off_rowsum);
     a.wg_grad = reinterpret_cast<float*>(ws + p.off_grad);
     const int nwg0 = p.row_blocks * p.col_splits;
+    const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
+    g_prof_start = g_prof_stop = nullptr;
+    if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
     if (d_z) TVAE_PROPAGATE(launch_tile_nb<true>(p.NB, a, 2 * nwg0, s));
     else TVAE_PROPAGATE(launch_tile_nb<false>(p.NB, a, 2 * nwg0, s));
+    if (ev1) TVAE_CHECK_HIP(hipEventRecord(ev1, s));
 
     FinalArgs f;
     f.wg_sums = a.wg_sums; f.nwg0 = nwg0; f.wg_rowsum = a.wg_rowsum; f.wg_grad = a.wg_grad; f.shift = shift; f.zp = zp;
