@@ -39,6 +39,7 @@ struct MmdArgs {
     const float* cnorm[2];   // squared norms (0 for padding rows)
     int n_rows, n_cols, row_offset;
     int row_blocks, col_splits, tiles_per_set, n_rows_pad;
+    int problem_base;        // first problem of this launch (0: rows = z, 1: rows = y)
     float inv_d2;
     double* wg_sums;         // [2 * row_blocks * col_splits][2]
     double* wg_rowsum;       // [col_splits][n_rows_pad]
@@ -58,20 +59,49 @@ __device__ __forceinline__ float em1_neg(float t) {
     return p * x;
 }
 
+// LDS-DMA of one row piece: lanes [0, nlanes) each move 16 B global -> LDS at lds_byte + 16*lane.
+// Issued from inline asm so that hipcc neither counts it in vmcnt bookkeeping nor drains it early;
+// M0 (the LDS base of the DMA) is written and restored inside the one statement (guide 5.7).
+// The source address is a wave-uniform SGPR base plus a per-lane 32-bit byte offset (saddr form), so
+// the row walk costs scalar adds only and no VGPRs.
+__device__ __forceinline__ void dma16(const float* sbase, unsigned voff, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma4(const float* sbase, unsigned voff, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+template <int NB>
+struct TileLds {
+    static constexpr int SW = 16 * NB;            // feature columns per wave
+    static constexpr int LDS_LD = SW + 4;         // padded row stride of a staged tile slice (floats)
+    static constexpr int SLICE = TILE_P * LDS_LD; // floats per wave per buffer
+    static constexpr int NORM_OFF = 2 * 4 * SLICE;             // [2 buf][4 waves][16] point norms
+    static constexpr int XCH_OFF = NORM_OFF + 2 * 4 * TILE_P;  // [2 buf][4 waves][2 tiles][64 lanes] float4
+    static constexpr int FLOATS = XCH_OFF + 2 * 4 * 2 * 64 * 4;
+    static constexpr int BYTES = FLOATS * 4;
+};
+
 template <int NB, bool GRAD>
-__global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
-    constexpr int SW = 16 * NB;       // feature columns per wave
-    constexpr int LDS_LD = SW + 4;    // padded row stride of the staged tile (floats)
-    constexpr int DPAD = 64 * NB;
+__global__ __launch_bounds__(256, (NB <= 6 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
+    using L = TileLds<NB>;
+    constexpr int SW = L::SW, LDS_LD = L::LDS_LD, DPAD = 64 * NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
-    float* xs = smem + wave * (TILE_P * LDS_LD);
-    f32x4* xch = reinterpret_cast<f32x4*>(smem + 4 * TILE_P * LDS_LD);
+    const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    f32x4* xch = reinterpret_cast<f32x4*>(smem + L::XCH_OFF);
 
     const int per_problem = a.row_blocks * a.col_splits;
-    const int bid = blockIdx.x;
-    const int problem = bid / per_problem;       // 0: rows = z (both column sets), 1: rows = y (y columns only)
+    // problem 0: rows = z against both column sets (+ gradient when GRAD); problem 1: rows = y against y.
+    // The GRAD instantiation is only ever launched for problem 0, so the gradient path is branch-free.
+    const int bid = a.problem_base * per_problem + blockIdx.x;
+    const int problem = GRAD ? 0 : bid / per_problem;
     const int rem = bid - problem * per_problem;
     const int rb = rem / a.col_splits, sp = rem - rb * a.col_splits;
     const int i0 = rb * ROWS_PER_WG;
@@ -94,6 +124,14 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void mmd_tile_kernel(MmdArg
         }
         rn[t] = valid_i[t] ? rnorm[row] : 0.f;
     }
+    // Retire these loads BEFORE the loop: otherwise hipcc must assume them pending at the loop header
+    // and waits vmcnt(0) at their first use in every iteration, draining the prefetch DMA it cannot see.
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int m = 0; m < NB; ++m) asm volatile("" : "+v"(zreg[t][m]));
+        asm volatile("" : "+v"(rn[t]));
+    }
 
     f32x4 acc[GRAD ? NB : 1][2];
     if (GRAD) {
@@ -103,7 +141,7 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void mmd_tile_kernel(MmdArg
             acc[db][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const bool do_grad = GRAD && problem == 0;
+    constexpr bool do_grad = GRAD;
 
     const long long tps = a.tiles_per_set;
     const long long total = problem == 0 ? 2 * tps : tps;
@@ -111,22 +149,38 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void mmd_tile_kernel(MmdArg
     const int tb = (int)(base + sp * total / a.col_splits);
     const int te = (int)(base + (sp + 1) * total / a.col_splits);
 
+    // Stage this wave's slice of point tile `tile` (16 rows x SW floats + 16 norms) into buffer `b`
+    // by LDS-DMA: one 16-B-per-lane instruction per row (4*NB lanes active), rows padded to LDS_LD.
+    // Rows past n_cols are zero in the padded copies, so no bounds checks are needed.
+    auto stage = [&](int tile, int b) {
+        const int set = tile >= tps ? 1 : 0;
+        const int p0 = (tile - set * (int)tps) * TILE_P;
+        const float* X = a.cols[set] + (long long)p0 * DPAD + wave * SW;     // wave-uniform
+        const unsigned dst = smem_byte + (unsigned)((b * 4 + wave) * L::SLICE) * 4u;
+        if (NB == 16 || lane < 4 * NB) {
+#pragma unroll
+            for (int row = 0; row < TILE_P; ++row)
+                dma16(X + (long long)row * DPAD, (unsigned)lane * 16u, dst + (unsigned)(row * LDS_LD) * 4u);
+        }
+        if (lane < TILE_P)
+            dma4(a.cnorm[set] + p0, (unsigned)lane * 4u, smem_byte + (unsigned)(L::NORM_OFF + (b * 4 + wave) * TILE_P) * 4u);
+    };
+
     double sum0 = 0.0, sum1 = 0.0;     // per-lane partial of sum E over set 0 / set 1
     double rowsum0 = 0.0, rowsum1 = 0.0;  // signed row sums R for the two 16-row groups
 
+    if (tb < te) stage(tb, 0);
     for (int tile = tb; tile < te; ++tile) {
         const int set = tile >= tps ? 1 : 0;
         const int p0 = (tile - set * (int)tps) * TILE_P;
-        const float* X = a.cols[set] + (long long)p0 * DPAD + wave * SW;
+        const int buf = (tile - tb) & 1;
+        const float* xs = smem + (buf * 4 + wave) * L::SLICE;
 
-        // 1. stage this wave's slice of the point tile (rows past n_cols are zero in the padded copy)
-#pragma unroll
-        for (int it = 0; it < NB; ++it) {
-            const int idx = it * 64 + lane;
-            const int row = idx / (4 * NB), c4 = idx - row * (4 * NB);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(X + (long long)row * DPAD + c4 * 4);
-            *reinterpret_cast<f32x4*>(xs + row * LDS_LD + c4 * 4) = v;
-        }
+        // 1. this tile's DMA has landed (wave-private data: the wave's own vmcnt is the only fence
+        //    needed); start the next tile's DMA into the other buffer — it flies during all of the
+        //    work below.  No compiler-visible VMEM op exists inside this loop.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tile + 1 < te) stage(tile + 1, buf ^ 1);
 
         // 2. partial Gram over the slice: S'[p][i], p = point (A rows), i = our rows (B columns)
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -140,19 +194,21 @@ __global__ __launch_bounds__(256, (NB <= 8 ? 2 : 1)) void mmd_tile_kernel(MmdArg
             }
         }
 
-        // 3. exchange the four slice partials (double-buffered: one barrier per tile)
-        const int buf = (tile - tb) & 1;
+        // 3. exchange the four slice partials (double-buffered: one barrier per tile; raw s_barrier
+        //    so that the in-flight DMA is not drained)
         f32x4* xb = xch + buf * (4 * 2 * 64);
         xb[(wave * 2 + 0) * 64 + lane] = s0;
         xb[(wave * 2 + 1) * 64 + lane] = s1;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         s0 = (xb[(0 * 2 + 0) * 64 + lane] + xb[(1 * 2 + 0) * 64 + lane]) +
              (xb[(2 * 2 + 0) * 64 + lane] + xb[(3 * 2 + 0) * 64 + lane]);
         s1 = (xb[(0 * 2 + 1) * 64 + lane] + xb[(1 * 2 + 1) * 64 + lane]) +
              (xb[(2 * 2 + 1) * 64 + lane] + xb[(3 * 2 + 1) * 64 + lane]);
 
         // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
-        const f32x4 cn = *reinterpret_cast<const f32x4*>(a.cnorm[set] + p0 + 4 * g);
+        const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + L::NORM_OFF + (buf * 4 + wave) * TILE_P + 4 * g);
         f32x4 t0, t1, e0, e1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -381,7 +437,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan*
 
 template <int NB, bool GRAD>
 int launch_tile(const MmdArgs& a, int nblocks, hipStream_t s) {
-    constexpr int lds_bytes = (4 * TILE_P * (16 * NB + 4) + 2 * 4 * 2 * 64 * 4) * 4;
+    constexpr int lds_bytes = TileLds<NB>::BYTES;
     static std::once_flag once;
     static hipError_t attr_status = hipSuccess;
     std::call_once(once, [] {
@@ -485,8 +541,15 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
-    if (d_z) TVAE_PROPAGATE(launch_tile_nb<true>(p.NB, a, 2 * nwg0, s));
-    else TVAE_PROPAGATE(launch_tile_nb<false>(p.NB, a, 2 * nwg0, s));
+    if (d_z) {
+        a.problem_base = 0;
+        TVAE_PROPAGATE(launch_tile_nb<true>(p.NB, a, nwg0, s));     // z rows: sums + gradient
+        a.problem_base = 1;
+        TVAE_PROPAGATE(launch_tile_nb<false>(p.NB, a, nwg0, s));    // y rows: sum only
+    } else {
+        a.problem_base = 0;
+        TVAE_PROPAGATE(launch_tile_nb<false>(p.NB, a, 2 * nwg0, s));
+    }
     if (ev1) TVAE_CHECK_HIP(hipEventRecord(ev1, s));
 
     FinalArgs f;
