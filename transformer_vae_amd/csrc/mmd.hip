@@ -59,43 +59,100 @@ __device__ __forceinline__ float em1_neg(float t) {
     return p * x;
 }
 
-// LDS-DMA of one row piece: lanes [0, nlanes) each move 16 B global -> LDS at lds_byte + 16*lane.
-// Issued from inline asm so that hipcc neither counts it in vmcnt bookkeeping nor drains it early;
-// M0 (the LDS base of the DMA) is written and restored inside the one statement (guide 5.7).
-// The source address is a wave-uniform SGPR base plus a per-lane 32-bit byte offset (saddr form), so
-// the row walk costs scalar adds only and no VGPRs.
+// LDS-DMA: every lane moves 16 B (dma16) or 4 B (dma4) global -> LDS at m0_base + lane*size.
+// Issued from inline asm so that hipcc neither counts it in its vmcnt bookkeeping nor drains it
+// early; M0 (the LDS base of the DMA) is written and restored inside the one statement (guide 5.7).
+// Source = wave-uniform SGPR base + per-lane 32-bit byte offset + immediate (saddr form): the tile
+// walk costs scalar adds only, and one VGPR holds the per-lane offset for the whole kernel.
+// (No instruction immediate: on LDS-DMA the offset field is added to the LDS address as well.)
+// The scalar operands go through readfirstlane: a no-op when hipcc already holds them in SGPRs, and
+// the only way to get them there when register pressure made it keep a wave-uniform value in VGPRs.
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void dma16(const float* sbase, unsigned voff, unsigned lds_byte) {
+    sbase = uniform_ptr(sbase);
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
 __device__ __forceinline__ void dma4(const float* sbase, unsigned voff, unsigned lds_byte) {
+    sbase = uniform_ptr(sbase);
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
 }
 
-template <int NB>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// n is a constant after loop unrolling; the switch folds to one s_waitcnt
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break;
+        case 15: wait_vmcnt<15>(); break; case 16: wait_vmcnt<16>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
+// LDS plan of mmd_tile_kernel.  A wave's slice of a point tile (16 points x SW floats) is stored
+// CHUNK-MAJOR and XOR-swizzled: 16-byte chunk j (4 floats) of point p lives at chunk position
+//     j * 16 + (p ^ (j & 3))
+// which (a) is one contiguous range, so NB full-width LDS-DMA instructions fill it (instruction i,
+// lane l brings chunk j = 4i + (l >> 4) of point p = (l & 15) ^ (l >> 4): the per-lane source offset
+// is the same for every instruction; the scalar base advances by 64 B), (b) makes the Gram operand
+// read (ds_read_b128, lane (p, g) reads chunk 4m+g of point p) and (c) the transposed gradient
+// operand read (ds_read_b32, lane (dc, g) reads feature 16 db + dc of point 4g + r) both bank-conflict
+// free.  DMA instruction i carries exactly the four chunk columns that Gram step m = i and gradient
+// block db = i consume, which is what makes the single tile buffer below refillable in place.
+template <int NB, int WAVES>
 struct TileLds {
-    static constexpr int SW = 16 * NB;            // feature columns per wave
-    static constexpr int LDS_LD = SW + 4;         // padded row stride of a staged tile slice (floats)
-    static constexpr int SLICE = TILE_P * LDS_LD; // floats per wave per buffer
-    static constexpr int NORM_OFF = 2 * 4 * SLICE;             // [2 buf][4 waves][16] point norms
-    static constexpr int XCH_OFF = NORM_OFF + 2 * 4 * TILE_P;  // [2 buf][4 waves][2 tiles][64 lanes] float4
-    static constexpr int FLOATS = XCH_OFF + 2 * 4 * 2 * 64 * 4;
+    static constexpr int SW = 16 * NB;                 // feature columns per wave
+    static constexpr int SLICE = TILE_P * SW;          // floats per wave (ONE tile buffer)
+    static constexpr int NORM_OFF = WAVES * SLICE;     // [2 buf][WAVES][16] point norms
+    static constexpr int XCH_OFF = NORM_OFF + 2 * WAVES * TILE_P;
+    static constexpr int XCH_ONE = WAVES * 2 * 64 * 4; // floats of one exchange buffer: [WAVES][2 tiles][64 lanes] float4
+    static constexpr int FLOATS = XCH_OFF + 2 * XCH_ONE;
     static constexpr int BYTES = FLOATS * 4;
+    static_assert(BYTES <= 160 * 1024, "tile kernel exceeds the 160 KiB LDS");
+    // workgroups per CU the LDS admits; the kernel is written to live with two waves per SIMD from
+    // DIFFERENT workgroups (independent phases), so the exchange / expm1 / DMA issue of one hide
+    // behind the MFMAs of the other
+    static constexpr int WG_PER_CU = (160 * 1024) / BYTES;
 };
 
-template <int NB, bool GRAD>
-__global__ __launch_bounds__(256, (NB <= 6 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
-    using L = TileLds<NB>;
-    constexpr int SW = L::SW, LDS_LD = L::LDS_LD, DPAD = 64 * NB;
+// One workgroup = WAVES waves owns 32 rows i of the kernel matrix and walks 16-point column tiles;
+// the feature dimension is sliced over the waves (DPAD = WAVES * SW).
+//
+// Single tile buffer, refilled in place: as soon as the LAST consumer of chunk-column block i of
+// tile k (gradient block db = i; Gram step m = i in the sum-only instantiation) has issued its
+// MFMAs, DMA instruction i of tile k+1 is issued into the same LDS bytes.  The Gram of tile k+1
+// waits with a COUNTED vmcnt in front of each operand read (DMAs retire in order), so every DMA has
+// between one and two phases to land and nothing is ever drained.  Slices and norms are wave-private:
+// the only workgroup barrier per tile is the one of the partial-S' exchange.
+template <int NB, int WAVES, bool GRAD>
+__global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
+    using L = TileLds<NB, WAVES>;
+    constexpr int SW = L::SW, DPAD = WAVES * SW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     f32x4* xch = reinterpret_cast<f32x4*>(smem + L::XCH_OFF);
+    const float* xs = smem + wave * L::SLICE;
+    const unsigned xs_byte = smem_byte + (unsigned)(wave * L::SLICE) * 4u;
 
     const int per_problem = a.row_blocks * a.col_splits;
     // problem 0: rows = z against both column sets (+ gradient when GRAD); problem 1: rows = y against y.
@@ -125,7 +182,7 @@ __global__ __launch_bounds__(256, (NB <= 6 ? 2 : 1)) void mmd_tile_kernel(MmdArg
         rn[t] = valid_i[t] ? rnorm[row] : 0.f;
     }
     // Retire these loads BEFORE the loop: otherwise hipcc must assume them pending at the loop header
-    // and waits vmcnt(0) at their first use in every iteration, draining the prefetch DMA it cannot see.
+    // and waits vmcnt(0) at their first use in every iteration, draining the DMA it cannot see.
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -141,7 +198,6 @@ __global__ __launch_bounds__(256, (NB <= 6 ? 2 : 1)) void mmd_tile_kernel(MmdArg
             acc[db][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    constexpr bool do_grad = GRAD;
 
     const long long tps = a.tiles_per_set;
     const long long total = problem == 0 ? 2 * tps : tps;
@@ -149,66 +205,95 @@ __global__ __launch_bounds__(256, (NB <= 6 ? 2 : 1)) void mmd_tile_kernel(MmdArg
     const int tb = (int)(base + sp * total / a.col_splits);
     const int te = (int)(base + (sp + 1) * total / a.col_splits);
 
-    // Stage this wave's slice of point tile `tile` (16 rows x SW floats + 16 norms) into buffer `b`
-    // by LDS-DMA: one 16-B-per-lane instruction per row (4*NB lanes active), rows padded to LDS_LD.
-    // Rows past n_cols are zero in the padded copies, so no bounds checks are needed.
-    auto stage = [&](int tile, int b) {
+    // per-lane constants of the swizzled image (see TileLds)
+    const unsigned dma_voff = (unsigned)((i16 ^ g) * DPAD + 4 * g) * 4u;     // source byte offset of DMA 0
+    const int gram_off = 64 * g + 4 * (i16 ^ g);                            // + 256 m   (floats)
+    const int c4 = i16 >> 2;                                                 // chunk column of this lane's feature
+    int grad_off[4];                                                         // + 256 db  (floats)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) grad_off[r] = 64 * c4 + 16 * g + 4 * (r ^ c4) + (i16 & 3);
+
+    // wave-uniform source of this wave's slice of point tile `tile` (rows past n_cols are zero in the
+    // padded copies, so no bounds checks are needed), and its norms
+    auto tile_src = [&](int tile) -> const float* {
         const int set = tile >= tps ? 1 : 0;
         const int p0 = (tile - set * (int)tps) * TILE_P;
-        const float* X = a.cols[set] + (long long)p0 * DPAD + wave * SW;     // wave-uniform
-        const unsigned dst = smem_byte + (unsigned)((b * 4 + wave) * L::SLICE) * 4u;
-        if (NB == 16 || lane < 4 * NB) {
-#pragma unroll
-            for (int row = 0; row < TILE_P; ++row)
-                dma16(X + (long long)row * DPAD, (unsigned)lane * 16u, dst + (unsigned)(row * LDS_LD) * 4u);
-        }
-        if (lane < TILE_P)
-            dma4(a.cnorm[set] + p0, (unsigned)lane * 4u, smem_byte + (unsigned)(L::NORM_OFF + (b * 4 + wave) * TILE_P) * 4u);
+        return a.cols[set] + (long long)p0 * DPAD + wave * SW;
+    };
+    auto stage_norms = [&](int tile, int nbuf) {
+        const int set = tile >= tps ? 1 : 0;
+        const int p0 = (tile - set * (int)tps) * TILE_P;
+        // scalar operands are pinned to SGPRs OUTSIDE the lane-masked region (inside it hipcc may
+        // rematerialise them in VGPRs, which the asm's "s" constraints cannot take)
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            smem_byte + (unsigned)(L::NORM_OFF + (nbuf * WAVES + wave) * TILE_P) * 4u);
+        const float* src = uniform_ptr(a.cnorm[set] + p0);
+        if (lane < TILE_P) dma4(src, (unsigned)lane * 4u, dst);
     };
 
     double sum0 = 0.0, sum1 = 0.0;     // per-lane partial of sum E over set 0 / set 1
     double rowsum0 = 0.0, rowsum1 = 0.0;  // signed row sums R for the two 16-row groups
 
-    if (tb < te) stage(tb, 0);
+    // DMA issue order per tile k: norms(k) ... X(k) blocks 0..NB-1 ... ; norms(k+1) goes out at the top of
+    // iteration k.  The counted waits below rely on exactly this order.
+    if (tb < te) {
+        stage_norms(tb, 0);
+        const float* X0 = tile_src(tb);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) dma16(X0 + 16 * i, dma_voff, xs_byte + 1024u * i);
+    }
     for (int tile = tb; tile < te; ++tile) {
         const int set = tile >= tps ? 1 : 0;
         const int p0 = (tile - set * (int)tps) * TILE_P;
         const int buf = (tile - tb) & 1;
-        const float* xs = smem + (buf * 4 + wave) * L::SLICE;
+        const bool has_next = tile + 1 < te;
+        const float* Xn = tile_src(has_next ? tile + 1 : tile);
+        if (has_next) stage_norms(tile + 1, buf ^ 1);
+        else wait_vmcnt<0>();   // last tile: fewer younger DMAs exist than the counted waits assume -> drain
 
-        // 1. this tile's DMA has landed (wave-private data: the wave's own vmcnt is the only fence
-        //    needed); start the next tile's DMA into the other buffer — it flies during all of the
-        //    work below.  No compiler-visible VMEM op exists inside this loop.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tile + 1 < te) stage(tile + 1, buf ^ 1);
-
-        // 2. partial Gram over the slice: S'[p][i], p = point (A rows), i = our rows (B columns)
+        // 1+2. partial Gram over the slice: S'[p][i], p = point (A rows), i = our rows (B columns).
+        //      Before the read of block m: all but the (younger) DMAs still allowed in flight have landed.
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        wait_vmcnt<NB>();                       // block 0 of this tile (and its norms) are in LDS
+        f32x4 av = *reinterpret_cast<const f32x4*>(xs + gram_off);
 #pragma unroll
         for (int m = 0; m < NB; ++m) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(xs + i16 * LDS_LD + 16 * m + 4 * g);
+            f32x4 avn = av;
+            if (m + 1 < NB) {
+                wait_vmcnt_n(GRAD ? NB - (m + 1) : NB - 1);
+                avn = *reinterpret_cast<const f32x4*>(xs + gram_off + 256 * (m + 1));
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], zreg[0][m][q], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], zreg[1][m][q], s1, 0, 0, 0);
             }
+            if (!GRAD) {
+                // sum-only: block m is dead once its MFMAs are issued -> refill it with the next tile
+                asm volatile("" ::"v"(s0), "v"(s1));
+                if (has_next) dma16(Xn + 16 * m, dma_voff, xs_byte + 1024u * m);
+            }
+            av = avn;
         }
 
-        // 3. exchange the four slice partials (double-buffered: one barrier per tile; raw s_barrier
-        //    so that the in-flight DMA is not drained)
-        f32x4* xb = xch + buf * (4 * 2 * 64);
+        // 3. exchange the slice partials through LDS (raw s_barrier: no vmcnt drain); double buffered,
+        //    so one barrier per tile
+        f32x4* xb = xch + buf * (L::XCH_ONE / 4);
         xb[(wave * 2 + 0) * 64 + lane] = s0;
         xb[(wave * 2 + 1) * 64 + lane] = s1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        s0 = (xb[(0 * 2 + 0) * 64 + lane] + xb[(1 * 2 + 0) * 64 + lane]) +
-             (xb[(2 * 2 + 0) * 64 + lane] + xb[(3 * 2 + 0) * 64 + lane]);
-        s1 = (xb[(0 * 2 + 1) * 64 + lane] + xb[(1 * 2 + 1) * 64 + lane]) +
-             (xb[(2 * 2 + 1) * 64 + lane] + xb[(3 * 2 + 1) * 64 + lane]);
+        s0 = xb[(0 * 2 + 0) * 64 + lane];
+        s1 = xb[(0 * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {      // fixed order: identical in every wave, deterministic
+            s0 += xb[(w * 2 + 0) * 64 + lane];
+            s1 += xb[(w * 2 + 1) * 64 + lane];
+        }
 
         // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
-        const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + L::NORM_OFF + (buf * 4 + wave) * TILE_P + 4 * g);
+        const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g);
         f32x4 t0, t1, e0, e1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -245,20 +330,31 @@ __global__ __launch_bounds__(256, (NB <= 6 ? 2 : 1)) void mmd_tile_kernel(MmdArg
             rowsum1 += (double)es1;
         }
 
-        // 5. gradient accumulation: acc^T[d][i] += sum_p X[p][d] * (s_p E'[p][i])
-        if (do_grad) {
+        // 5. gradient accumulation: acc^T[d][i] += sum_p X[p][d] * (s_p E'[p][i]); block db of the tile is
+        //    dead after its MFMAs -> DMA block db of the NEXT tile over it (operand reads run one block ahead)
+        if (GRAD) {
             if (set) { e0 = -e0; e1 = -e1; }
+            float ga[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[r] = xs[grad_off[r]];
 #pragma unroll
             for (int db = 0; db < NB; ++db) {
+                float gn[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gn[r] = (db + 1 < NB) ? xs[grad_off[r] + 256 * (db + 1)] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float av = xs[(4 * g + r) * LDS_LD + 16 * db + i16];
-                    acc[db][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, e0[r], acc[db][0], 0, 0, 0);
-                    acc[db][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, e1[r], acc[db][1], 0, 0, 0);
+                    acc[db][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r], e0[r], acc[db][0], 0, 0, 0);
+                    acc[db][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r], e1[r], acc[db][1], 0, 0, 0);
                 }
+                asm volatile("" ::"v"(acc[db][0]), "v"(acc[db][1]));   // MFMAs of block db are issued before its refill
+                if (has_next) dma16(Xn + 16 * db, dma_voff, xs_byte + 1024u * db);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ga[r] = gn[r];
             }
         }
     }
+    wait_vmcnt<0>();
 
     // ---- per-workgroup results (every wave holds identical sums; wave 0 writes) ----
     const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
@@ -266,7 +362,7 @@ __global__ __launch_bounds__(256, (NB <= 6 ? 2 : 1)) void mmd_tile_kernel(MmdArg
         a.wg_sums[2 * (long long)bid + 0] = w0;
         a.wg_sums[2 * (long long)bid + 1] = w1;
     }
-    if (do_grad) {
+    if (GRAD) {
         double r0v = rowsum0, r1v = rowsum1;
         r0v += __shfl_xor(r0v, 16, 64); r0v += __shfl_xor(r0v, 32, 64);
         r1v += __shfl_xor(r1v, 16, 64); r1v += __shfl_xor(r1v, 32, 64);
@@ -390,21 +486,26 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
 
 // ---- host side ------------------------------------------------------------------------
 struct Plan {
-    int NB, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
+    int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
     int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_sums, off_rowsum, off_grad, bytes;
 };
 
-int pick_nb(int64_t D) {
-    static const int opts[] = {1, 2, 3, 4, 6, 8, 12, 16};
-    for (int nb : opts)
-        if (64 * nb >= D) return nb;
-    return 0;
+// (padded dimension, waves per workgroup, 16-column blocks per wave); DPAD = WAVES * 16 * NB
+struct Shape { int dpad, waves, nb; };
+const Shape kShapes[] = {{64, 4, 1}, {128, 4, 2}, {192, 4, 3}, {256, 4, 4}, {384, 4, 6},
+                         {512, 4, 8}, {768, 4, 12}, {1024, 8, 8}};
+const Shape* pick_shape(int64_t D) {
+    for (const Shape& sh : kShapes)
+        if (sh.dpad >= D) return &sh;
+    return nullptr;
 }
 
 bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan* p) {
-    p->NB = pick_nb(D);
-    if (p->NB == 0) return false;
-    p->DPAD = 64 * p->NB;
+    const Shape* sh = pick_shape(D);
+    if (!sh) return false;
+    p->NB = sh->nb;
+    p->WAVES = sh->waves;
+    p->DPAD = sh->dpad;
     p->n_pad = (int)align_up(n_total, TILE_P);
     p->row_blocks = (int)((n_rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
     p->n_rows_pad = p->row_blocks * ROWS_PER_WG;
@@ -435,34 +536,34 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan*
     return true;
 }
 
-template <int NB, bool GRAD>
+template <int NB, int WAVES, bool GRAD>
 int launch_tile(const MmdArgs& a, int nblocks, hipStream_t s) {
-    constexpr int lds_bytes = TileLds<NB>::BYTES;
+    constexpr int lds_bytes = TileLds<NB, WAVES>::BYTES;
     static std::once_flag once;
     static hipError_t attr_status = hipSuccess;
     std::call_once(once, [] {
-        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_tile_kernel<NB, GRAD>),
+        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_tile_kernel<NB, WAVES, GRAD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     });
     TVAE_CHECK_HIP(attr_status);
-    hipLaunchKernelGGL((mmd_tile_kernel<NB, GRAD>), dim3(nblocks), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL((mmd_tile_kernel<NB, WAVES, GRAD>), dim3(nblocks), dim3(64 * WAVES), lds_bytes, s, a);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }
 
 template <bool GRAD>
-int launch_tile_nb(int NB, const MmdArgs& a, int nblocks, hipStream_t s) {
-    switch (NB) {
-        case 1: return launch_tile<1, GRAD>(a, nblocks, s);
-        case 2: return launch_tile<2, GRAD>(a, nblocks, s);
-        case 3: return launch_tile<3, GRAD>(a, nblocks, s);
-        case 4: return launch_tile<4, GRAD>(a, nblocks, s);
-        case 6: return launch_tile<6, GRAD>(a, nblocks, s);
-        case 8: return launch_tile<8, GRAD>(a, nblocks, s);
-        case 12: return launch_tile<12, GRAD>(a, nblocks, s);
-        case 16: return launch_tile<16, GRAD>(a, nblocks, s);
+int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
+    switch (dpad) {
+        case 64: return launch_tile<1, 4, GRAD>(a, nblocks, s);
+        case 128: return launch_tile<2, 4, GRAD>(a, nblocks, s);
+        case 192: return launch_tile<3, 4, GRAD>(a, nblocks, s);
+        case 256: return launch_tile<4, 4, GRAD>(a, nblocks, s);
+        case 384: return launch_tile<6, 4, GRAD>(a, nblocks, s);
+        case 512: return launch_tile<8, 4, GRAD>(a, nblocks, s);
+        case 768: return launch_tile<12, 4, GRAD>(a, nblocks, s);
+        case 1024: return launch_tile<8, 8, GRAD>(a, nblocks, s);
     }
-    return fail(TVAE_ERR_ARG, "mmd: no kernel for NB=%d", NB);
+    return fail(TVAE_ERR_ARG, "mmd: no kernel for padded dimension %d", dpad);
 }
 
 }  // namespace
@@ -518,10 +619,10 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     dim3 pgrid((p.nwaves + 3) / 4, 2);
     if (dtype == TVAE_F32)
         hipLaunchKernelGGL(mmd_prep_kernel<float>, pgrid, dim3(256), 0, s, (const float*)z_all, (const float*)y_all,
-                           (int)n_total, p.n_pad, (int)D, p.NB, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
+                           (int)n_total, p.n_pad, (int)D, p.DPAD / 64, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
     else
         hipLaunchKernelGGL(mmd_prep_kernel<bf16>, pgrid, dim3(256), 0, s, (const bf16*)z_all, (const bf16*)y_all,
-                           (int)n_total, p.n_pad, (int)D, p.NB, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
+                           (int)n_total, p.n_pad, (int)D, p.DPAD / 64, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
     TVAE_CHECK_HIP(hipGetLastError());
     if (d_z) {
         hipLaunchKernelGGL(mmd_shift_kernel, dim3((p.DPAD + 255) / 256), dim3(256), 0, s, colpart, p.nwaves, p.DPAD, shift);
@@ -543,12 +644,12 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
     if (d_z) {
         a.problem_base = 0;
-        TVAE_PROPAGATE(launch_tile_nb<true>(p.NB, a, nwg0, s));     // z rows: sums + gradient
+        TVAE_PROPAGATE(launch_tile_shape<true>(p.DPAD, a, nwg0, s));              // z rows: sums + gradient
         a.problem_base = 1;
-        TVAE_PROPAGATE(launch_tile_nb<false>(p.NB, a, nwg0, s));    // y rows: sum only
+        TVAE_PROPAGATE(launch_tile_shape<false>(p.DPAD, a, nwg0, s));    // y rows: sum only
     } else {
         a.problem_base = 0;
-        TVAE_PROPAGATE(launch_tile_nb<false>(p.NB, a, 2 * nwg0, s));
+        TVAE_PROPAGATE(launch_tile_shape<false>(p.DPAD, a, 2 * nwg0, s));
     }
     if (ev1) TVAE_CHECK_HIP(hipEventRecord(ev1, s));
 
