@@ -40,6 +40,7 @@ struct MmdArgs {
     int n_rows, n_cols, row_offset;
     int row_blocks, col_splits, tiles_per_set, n_rows_pad;
     int problem_base;        // first problem of this launch (0: rows = z, 1: rows = y)
+    int sym;                 // 1: the y-y problem visits each unordered pair of 32-row blocks once (weight 2)
     float inv_d2;
     double* wg_sums;         // [2 * row_blocks * col_splits][2]
     double* wg_rowsum;       // [col_splits][n_rows_pad]
@@ -200,10 +201,26 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
     }
 
     const long long tps = a.tiles_per_set;
-    const long long total = problem == 0 ? 2 * tps : tps;
-    const long long base = problem == 0 ? 0 : tps;
+    // Kyy is symmetric: with 32-point column blocks J (two tiles each) and this workgroup's global row
+    // block I, the pair {I, J} is evaluated from I's side iff J == I (weight 1) or
+    // (I < J) == ((I + J) even) (weight 2).  Every unordered pair is then visited exactly once, and the
+    // work per row block is balanced (which matters when ranks own contiguous row ranges).
+    const bool sym = !GRAD && problem == 1 && a.sym;
+    const int blkI = (a.row_offset >> 5) + rb;
+    const int nJ = (int)(tps >> 1);
+    const int symA = (blkI + 1) >> 1;                                   // # of J < I with parity != I's
+    const int symM = symA + 1 + ((nJ - 1 - blkI) >> 1);                 // + J == I + # of J > I, same parity
+    const long long total = problem == 0 ? 2 * tps : (sym ? 2 * (long long)symM : tps);
+    const long long base = (problem == 0 || sym) ? 0 : tps;
     const int tb = (int)(base + sp * total / a.col_splits);
     const int te = (int)(base + (sp + 1) * total / a.col_splits);
+    // loop index -> tile index in [0, 2 tps)
+    auto actual = [&](int vt) -> int {
+        if (!sym) return vt;
+        const int q = vt >> 1;
+        const int J = q < symA ? ((blkI + 1) & 1) + 2 * q : (q == symA ? blkI : blkI + 2 * (q - symA));
+        return (int)tps + 2 * J + (vt & 1);
+    };
 
     // per-lane constants of the swizzled image (see TileLds)
     const unsigned dma_voff = (unsigned)((i16 ^ g) * DPAD + 4 * g) * 4u;     // source byte offset of DMA 0
@@ -215,12 +232,14 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 
     // wave-uniform source of this wave's slice of point tile `tile` (rows past n_cols are zero in the
     // padded copies, so no bounds checks are needed), and its norms
-    auto tile_src = [&](int tile) -> const float* {
+    auto tile_src = [&](int vt) -> const float* {
+        const int tile = actual(vt);
         const int set = tile >= tps ? 1 : 0;
         const int p0 = (tile - set * (int)tps) * TILE_P;
         return a.cols[set] + (long long)p0 * DPAD + wave * SW;
     };
-    auto stage_norms = [&](int tile, int nbuf) {
+    auto stage_norms = [&](int vt, int nbuf) {
+        const int tile = actual(vt);
         const int set = tile >= tps ? 1 : 0;
         const int p0 = (tile - set * (int)tps) * TILE_P;
         // scalar operands are pinned to SGPRs OUTSIDE the lane-masked region (inside it hipcc may
@@ -243,8 +262,10 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         for (int i = 0; i < NB; ++i) dma16(X0 + 16 * i, dma_voff, xs_byte + 1024u * i);
     }
     for (int tile = tb; tile < te; ++tile) {
-        const int set = tile >= tps ? 1 : 0;
-        const int p0 = (tile - set * (int)tps) * TILE_P;
+        const int atile = actual(tile);
+        const int set = atile >= tps ? 1 : 0;
+        const int p0 = (atile - set * (int)tps) * TILE_P;
+        const float wsym = (sym && (p0 >> 5) != blkI) ? 2.f : 1.f;
         const int buf = (tile - tb) & 1;
         const bool has_next = tile + 1 < te;
         const float* Xn = tile_src(has_next ? tile + 1 : tile);
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         const float es0 = (e0[0] + e0[1]) + (e0[2] + e0[3]);
         const float es1 = (e1[0] + e1[1]) + (e1[2] + e1[3]);
         if (set) {
-            sum1 += (double)(es0 + es1);
+            sum1 += (double)(wsym * (es0 + es1));
             rowsum0 -= (double)es0;
             rowsum1 -= (double)es1;
         } else {
@@ -422,15 +443,24 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
         if (j < NB) cp[lane + 64 * j] = csum[j];
 }
 
-// shift[c] = sum_rows z[.,c] - sum_rows y[.,c]  (fp64 accumulate over the per-wave partials)
-__global__ __launch_bounds__(256) void mmd_shift_kernel(const float* __restrict__ colpart, int nwaves, int DPAD,
-                                                        float* __restrict__ shift) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= DPAD) return;
+// shift[c] = sum_rows z[.,c] - sum_rows y[.,c]  (fp64 accumulate over the per-wave partials).
+// One workgroup per 64 columns; 16 row-lanes stride over the partials, then a fixed-order LDS reduction.
+__global__ __launch_bounds__(1024) void mmd_shift_kernel(const float* __restrict__ colpart, int nwaves, int DPAD,
+                                                         float* __restrict__ shift) {
+    __shared__ double red[16][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     double s = 0.0;
-    for (int w = 0; w < nwaves; ++w)
+    for (int w = ry; w < nwaves; w += 16)
         s += (double)colpart[(long long)w * DPAD + c] - (double)colpart[((long long)nwaves + w) * DPAD + c];
-    shift[c] = (float)s;
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        shift[c] = (float)t;
+    }
 }
 
 struct FinalArgs {
@@ -506,7 +536,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan*
     p->NB = sh->nb;
     p->WAVES = sh->waves;
     p->DPAD = sh->dpad;
-    p->n_pad = (int)align_up(n_total, TILE_P);
+    p->n_pad = (int)align_up(n_total, 2 * TILE_P);   // whole 32-point blocks (symmetric y-y enumeration)
     p->row_blocks = (int)((n_rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
     p->n_rows_pad = p->row_blocks * ROWS_PER_WG;
     p->tiles_per_set = p->n_pad / TILE_P;
@@ -625,7 +655,7 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
                            (int)n_total, p.n_pad, (int)D, p.DPAD / 64, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
     TVAE_CHECK_HIP(hipGetLastError());
     if (d_z) {
-        hipLaunchKernelGGL(mmd_shift_kernel, dim3((p.DPAD + 255) / 256), dim3(256), 0, s, colpart, p.nwaves, p.DPAD, shift);
+        hipLaunchKernelGGL(mmd_shift_kernel, dim3(p.DPAD / 64), dim3(1024), 0, s, colpart, p.nwaves, p.DPAD, shift);
         TVAE_CHECK_HIP(hipGetLastError());
     }
 
@@ -635,6 +665,7 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     a.row_blocks = p.row_blocks; a.col_splits = p.col_splits; a.tiles_per_set = p.tiles_per_set;
     a.n_rows_pad = p.n_rows_pad;
     a.inv_d2 = (float)(1.0 / ((double)D * (double)D));
+    a.sym = (row_offset % ROWS_PER_WG == 0 && (n_rows % ROWS_PER_WG == 0 || row_offset + n_rows == n_total)) ? 1 : 0;
     a.wg_sums = reinterpret_cast<double*>(ws + p.off_sums);
     a.wg_rowsum = reinterpret_cast<double*>(ws + p.off_rowsum);
     a.wg_grad = reinterpret_cast<float*>(ws + p.off_grad);
