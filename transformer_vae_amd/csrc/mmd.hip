@@ -299,18 +299,21 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 
         // 3. exchange the slice partials through LDS (raw s_barrier: no vmcnt drain); double buffered,
         //    so one barrier per tile
-        f32x4* xb = xch + buf * (L::XCH_ONE / 4);
-        xb[(wave * 2 + 0) * 64 + lane] = s0;
-        xb[(wave * 2 + 1) * 64 + lane] = s1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        s0 = xb[(0 * 2 + 0) * 64 + lane];
-        s1 = xb[(0 * 2 + 1) * 64 + lane];
+        //    (WAVES == 1: narrow latents — one wave holds the whole feature dimension, nothing to exchange)
+        if (WAVES > 1) {
+            f32x4* xb = xch + buf * (L::XCH_ONE / 4);
+            xb[(wave * 2 + 0) * 64 + lane] = s0;
+            xb[(wave * 2 + 1) * 64 + lane] = s1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            s0 = xb[(0 * 2 + 0) * 64 + lane];
+            s1 = xb[(0 * 2 + 1) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) {      // fixed order: identical in every wave, deterministic
-            s0 += xb[(w * 2 + 0) * 64 + lane];
-            s1 += xb[(w * 2 + 1) * 64 + lane];
+            for (int w = 1; w < WAVES; ++w) {      // fixed order: identical in every wave, deterministic
+                s0 += xb[(w * 2 + 0) * 64 + lane];
+                s1 += xb[(w * 2 + 1) * 64 + lane];
+            }
         }
 
         // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 // ---- prep: fp32 zero-padded copies (row stride DPAD), squared norms, per-wave column sums ----
 template <typename T>
 __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, const T* __restrict__ y, int n_total,
-                                                       int n_pad, int D, int NB, float* __restrict__ zp,
+                                                       int n_pad, int D, int DPAD, float* __restrict__ zp,
                                                        float* __restrict__ yp, float* __restrict__ zn,
                                                        float* __restrict__ yn, float* __restrict__ colpart,
                                                        int rows_per_wave, int nwaves) {
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
     const T* __restrict__ src = set ? y : z;
     float* __restrict__ dst = set ? yp : zp;
     float* __restrict__ nrm = set ? yn : zn;
-    const int DPAD = 64 * NB;
+    const int NJ = (DPAD + 63) / 64;      // 64-column groups per row (<= 16)
     float csum[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) csum[j] = 0.f;
@@ -426,8 +429,8 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
         float sq = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (j < NB) {
-                const int c = lane + 64 * j;
+            const int c = lane + 64 * j;
+            if (j < NJ && c < DPAD) {
                 const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
                 dst[(long long)row * DPAD + c] = v;
                 csum[j] += v;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
     float* cp = colpart + ((long long)set * nwaves + wg) * DPAD;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-        if (j < NB) cp[lane + 64 * j] = csum[j];
+        if (j < NJ && lane + 64 * j < DPAD) cp[lane + 64 * j] = csum[j];
 }
 
 // shift[c] = sum_rows z[.,c] - sum_rows y[.,c]  (fp64 accumulate over the per-wave partials).
@@ -451,11 +454,12 @@ __global__ __launch_bounds__(1024) void mmd_shift_kernel(const float* __restrict
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double s = 0.0;
-    for (int w = ry; w < nwaves; w += 16)
-        s += (double)colpart[(long long)w * DPAD + c] - (double)colpart[((long long)nwaves + w) * DPAD + c];
+    if (c < DPAD)
+        for (int w = ry; w < nwaves; w += 16)
+            s += (double)colpart[(long long)w * DPAD + c] - (double)colpart[((long long)nwaves + w) * DPAD + c];
     red[ry][cx] = s;
     __syncthreads();
-    if (ry == 0) {
+    if (ry == 0 && c < DPAD) {
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][cx];
@@ -522,7 +526,10 @@ struct Plan {
 
 // (padded dimension, waves per workgroup, 16-column blocks per wave); DPAD = WAVES * 16 * NB
 struct Shape { int dpad, waves, nb; };
-const Shape kShapes[] = {{64, 4, 1}, {128, 4, 2}, {192, 4, 3}, {256, 4, 4}, {384, 4, 6},
+// Narrow latents (<= 192): one wave per workgroup owns all features of its 32 rows (no exchange, no
+// barrier); wider ones slice the features over 4 (8) waves.
+const Shape kShapes[] = {{16, 1, 1}, {32, 1, 2}, {48, 1, 3}, {64, 1, 4}, {80, 1, 5}, {96, 1, 6}, {112, 1, 7},
+                         {128, 1, 8}, {160, 1, 10}, {192, 1, 12}, {256, 4, 4}, {384, 4, 6},
                          {512, 4, 8}, {768, 4, 12}, {1024, 8, 8}};
 const Shape* pick_shape(int64_t D) {
     for (const Shape& sh : kShapes)
@@ -541,7 +548,8 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan*
     p->n_rows_pad = p->row_blocks * ROWS_PER_WG;
     p->tiles_per_set = p->n_pad / TILE_P;
     int cs = 1;
-    if (p->row_blocks < 512) cs = (512 + p->row_blocks - 1) / p->row_blocks;
+    const int want_wgs = 2048 / p->WAVES;      // >= 8 waves per CU per problem
+    if (p->row_blocks < want_wgs) cs = (want_wgs + p->row_blocks - 1) / p->row_blocks;
     const int max_cs = p->tiles_per_set >= 4 ? p->tiles_per_set / 4 : 1;
     if (cs > max_cs) cs = max_cs;
     if (cs > 64) cs = 64;
@@ -584,9 +592,16 @@ int launch_tile(const MmdArgs& a, int nblocks, hipStream_t s) {
 template <bool GRAD>
 int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
     switch (dpad) {
-        case 64: return launch_tile<1, 4, GRAD>(a, nblocks, s);
-        case 128: return launch_tile<2, 4, GRAD>(a, nblocks, s);
-        case 192: return launch_tile<3, 4, GRAD>(a, nblocks, s);
+        case 16: return launch_tile<1, 1, GRAD>(a, nblocks, s);
+        case 32: return launch_tile<2, 1, GRAD>(a, nblocks, s);
+        case 48: return launch_tile<3, 1, GRAD>(a, nblocks, s);
+        case 64: return launch_tile<4, 1, GRAD>(a, nblocks, s);
+        case 80: return launch_tile<5, 1, GRAD>(a, nblocks, s);
+        case 96: return launch_tile<6, 1, GRAD>(a, nblocks, s);
+        case 112: return launch_tile<7, 1, GRAD>(a, nblocks, s);
+        case 128: return launch_tile<8, 1, GRAD>(a, nblocks, s);
+        case 160: return launch_tile<10, 1, GRAD>(a, nblocks, s);
+        case 192: return launch_tile<12, 1, GRAD>(a, nblocks, s);
         case 256: return launch_tile<4, 4, GRAD>(a, nblocks, s);
         case 384: return launch_tile<6, 4, GRAD>(a, nblocks, s);
         case 512: return launch_tile<8, 4, GRAD>(a, nblocks, s);
@@ -649,13 +664,13 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     dim3 pgrid((p.nwaves + 3) / 4, 2);
     if (dtype == TVAE_F32)
         hipLaunchKernelGGL(mmd_prep_kernel<float>, pgrid, dim3(256), 0, s, (const float*)z_all, (const float*)y_all,
-                           (int)n_total, p.n_pad, (int)D, p.DPAD / 64, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
+                           (int)n_total, p.n_pad, (int)D, p.DPAD, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
     else
         hipLaunchKernelGGL(mmd_prep_kernel<bf16>, pgrid, dim3(256), 0, s, (const bf16*)z_all, (const bf16*)y_all,
-                           (int)n_total, p.n_pad, (int)D, p.DPAD / 64, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
+                           (int)n_total, p.n_pad, (int)D, p.DPAD, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
     TVAE_CHECK_HIP(hipGetLastError());
     if (d_z) {
-        hipLaunchKernelGGL(mmd_shift_kernel, dim3(p.DPAD / 64), dim3(1024), 0, s, colpart, p.nwaves, p.DPAD, shift);
+        hipLaunchKernelGGL(mmd_shift_kernel, dim3((p.DPAD + 63) / 64), dim3(1024), 0, s, colpart, p.nwaves, p.DPAD, shift);
         TVAE_CHECK_HIP(hipGetLastError());
     }
 
