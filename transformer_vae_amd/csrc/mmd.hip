@@ -547,12 +547,21 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan*
     p->row_blocks = (int)((n_rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
     p->n_rows_pad = p->row_blocks * ROWS_PER_WG;
     p->tiles_per_set = p->n_pad / TILE_P;
+    // Column splits: enough workgroups to fill the chip, and a count that fills the LAST round of
+    // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
+    const int wg_per_cu = p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1);
+    const int slots = 256 * wg_per_cu;
+    const int max_cs = p->tiles_per_set >= 64 ? (p->tiles_per_set / 32 < 64 ? p->tiles_per_set / 32 : 64)
+                                              : (p->tiles_per_set >= 4 ? p->tiles_per_set / 4 : 1);
     int cs = 1;
-    const int want_wgs = 2048 / p->WAVES;      // >= 8 waves per CU per problem
-    if (p->row_blocks < want_wgs) cs = (want_wgs + p->row_blocks - 1) / p->row_blocks;
-    const int max_cs = p->tiles_per_set >= 4 ? p->tiles_per_set / 4 : 1;
-    if (cs > max_cs) cs = max_cs;
-    if (cs > 64) cs = 64;
+    double best = 1e30;
+    for (int c = 1; c <= max_cs; ++c) {
+        const double rounds = (double)p->row_blocks * c / slots;
+        const double waste = (rounds < 1.0 ? 1.0 / rounds : ((double)(long long)(rounds + 0.999999)) / rounds);
+        // prefer fewer splits unless a larger count is at least 2 % better
+        if (waste < best * 0.98) { best = waste; cs = c; }
+        if (waste <= 1.0005) break;
+    }
     p->col_splits = cs < 1 ? 1 : cs;
     int rpw = (p->n_pad + 2047) / 2048;
     if (rpw < 4) rpw = 4;

@@ -94,14 +94,24 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ 
     }
 }
 
+// out[c] = sum over chunks (fp64, fixed order): 64 columns per workgroup, 16 row-lanes stride the chunks
 template <typename T>
-__global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict__ part, int chunks, int cols,
-                                                        T* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+__global__ __launch_bounds__(1024) void col_final_kernel(const float* __restrict__ part, int chunks, int cols,
+                                                         T* __restrict__ out) {
+    __shared__ double red[16][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     double s = 0.0;
-    for (int k = 0; k < chunks; ++k) s += (double)part[(long long)k * cols + c];
-    out[c] = from_f32<T>((float)s);
+    if (c < cols)
+        for (int k = ry; k < chunks; k += 16) s += (double)part[(long long)k * cols + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        out[c] = from_f32<T>((float)t);
+    }
 }
 
 template <typename T>
@@ -173,12 +183,12 @@ int colsum(const void* x, int64_t rows, int64_t cols, void* out, int dtype, floa
     if (dtype == TVAE_F32) {
         hipLaunchKernelGGL((col_partial_kernel<float, 0>), grid, dim3(256), 0, s, (const float*)x, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (long long)rows, (int)cols, scratch, (float*)nullptr);
-        hipLaunchKernelGGL(col_final_kernel<float>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, scratch, chunks,
+        hipLaunchKernelGGL(col_final_kernel<float>, dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, s, scratch, chunks,
                            (int)cols, (float*)out);
     } else {
         hipLaunchKernelGGL((col_partial_kernel<bf16, 0>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (long long)rows, (int)cols, scratch, (float*)nullptr);
-        hipLaunchKernelGGL(col_final_kernel<bf16>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, scratch, chunks,
+        hipLaunchKernelGGL(col_final_kernel<bf16>, dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, s, scratch, chunks,
                            (int)cols, (bf16*)out);
     }
     TVAE_CHECK_HIP(hipGetLastError());
@@ -192,17 +202,17 @@ int layernorm_bwd_params(const void* dout, const void* r, const float* mean, con
     float* p0 = scratch;
     float* p1 = scratch + (int64_t)chunks * d;
     dim3 grid((unsigned)((d + 63) / 64), (unsigned)chunks);
-    const dim3 fgrid((unsigned)((d + 255) / 256));
+    const dim3 fgrid((unsigned)((d + 63) / 64));
     if (dtype == TVAE_F32) {
         hipLaunchKernelGGL((col_partial_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)dout, (const float*)r, mean,
                            rstd, (long long)rows, (int)d, p0, p1);
-        hipLaunchKernelGGL(col_final_kernel<float>, fgrid, dim3(256), 0, s, p0, chunks, (int)d, (float*)dgamma);
-        hipLaunchKernelGGL(col_final_kernel<float>, fgrid, dim3(256), 0, s, p1, chunks, (int)d, (float*)dbeta);
+        hipLaunchKernelGGL(col_final_kernel<float>, fgrid, dim3(1024), 0, s, p0, chunks, (int)d, (float*)dgamma);
+        hipLaunchKernelGGL(col_final_kernel<float>, fgrid, dim3(1024), 0, s, p1, chunks, (int)d, (float*)dbeta);
     } else {
         hipLaunchKernelGGL((col_partial_kernel<bf16, 1>), grid, dim3(256), 0, s, (const bf16*)dout, (const bf16*)r, mean,
                            rstd, (long long)rows, (int)d, p0, p1);
-        hipLaunchKernelGGL(col_final_kernel<bf16>, fgrid, dim3(256), 0, s, p0, chunks, (int)d, (bf16*)dgamma);
-        hipLaunchKernelGGL(col_final_kernel<bf16>, fgrid, dim3(256), 0, s, p1, chunks, (int)d, (bf16*)dbeta);
+        hipLaunchKernelGGL(col_final_kernel<bf16>, fgrid, dim3(1024), 0, s, p0, chunks, (int)d, (bf16*)dgamma);
+        hipLaunchKernelGGL(col_final_kernel<bf16>, fgrid, dim3(1024), 0, s, p1, chunks, (int)d, (bf16*)dbeta);
     }
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;

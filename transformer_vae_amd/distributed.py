@@ -27,12 +27,26 @@ def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
     """Concatenate equally sized row blocks from every rank, in rank order."""
     world = dist.get_world_size(group)
     x = x.contiguous()
+    if x.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device collectives: rehearsal / test runs only (the product backend is RCCL)
+        return all_gather_rows(x.cpu(), group).to(x.device)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    try:
+    if x.is_cuda:
         dist.all_gather_into_tensor(out, x, group=group)
-    except (RuntimeError, NotImplementedError):
+    else:
         dist.all_gather(list(out.chunk(world, dim=0)), x, group=group)
     return out
+
+
+def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum over ranks, in place; returns x."""
+    if x.is_cuda and dist.get_backend(group) == "gloo":
+        c = x.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        x.copy_(c)
+        return x
+    dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+    return x
 
 
 def sharded_mmd_reg_loss(latent2d: torch.Tensor, prior_local: torch.Tensor, batch_size_local: int, n_latents: int,
@@ -56,8 +70,7 @@ def sharded_mmd_reg_loss(latent2d: torch.Tensor, prior_local: torch.Tensor, batc
     if compensate_ddp_mean:
         grad_scale *= world
     local, sums = fn(latent2d, z_all, y_all, rank * n_local, loss_scale, grad_scale)
-    sums = sums.detach().clone()
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    sums = all_reduce_sum(sums.detach().clone(), group)
     reg = ((sums[2] + sums[0] - 2.0 * sums[1]) * loss_scale).to(torch.float32)
     # value: the global loss; gradient: through this rank's row block only
     return reg.detach() + (local - local.detach())
