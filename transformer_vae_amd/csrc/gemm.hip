@@ -27,34 +27,49 @@ struct GemmArgs {
     int vecA, vecB;
 };
 
-// Stage a (64 rows x 32 k) operand tile into LDS as tile[k][row].
+// A (64 rows x 32 k) operand tile travels global -> registers -> LDS (as tile[k][row]) in two halves,
+// so that the global loads of tile t+1 are in flight while tile t is multiplied.
 template <typename T, bool KMAJOR>
-__device__ __forceinline__ void stage_tile(float (*tile)[LDS_LD], const T* __restrict__ P, const RowMap& map,
-                                           int r0, int R, int k0, int kend, bool vec, int tid) {
+__device__ __forceinline__ void tile_load(float v[2][4], const T* __restrict__ P, const RowMap& map, int r0, int R,
+                                          int k0, int kend, bool vec, int tid) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = tid + 256 * j;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = 0.f;
         if (!KMAJOR) {
             const int row = q >> 3, kq = (q & 7) * 4;
             const int r = r0 + row, k = k0 + kq;
             if (r < R && k < kend) {
                 const T* p = P + map(r) + k;
                 const int nv = min(4, kend - k);
-                if (vec && nv == 4) load4_vec(p, v); else load4_guard(p, nv, v);
+                if (vec && nv == 4) load4_vec(p, v[j]); else load4_guard(p, nv, v[j]);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tile[kq + e][row] = v[e];
         } else {
             const int krow = q >> 4, rq = (q & 15) * 4;
             const int k = k0 + krow, r = r0 + rq;
             if (k < kend && r < R) {
                 const T* p = P + map(k) + r;
                 const int nv = min(4, R - r);
-                if (vec && nv == 4) load4_vec(p, v); else load4_guard(p, nv, v);
+                if (vec && nv == 4) load4_vec(p, v[j]); else load4_guard(p, nv, v[j]);
             }
+        }
+    }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_store(float (*tile)[LDS_LD], const float v[2][4], int tid) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tile[krow][rq + e] = v[e];
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + 256 * j;
+        if (!KMAJOR) {
+            const int row = q >> 3, kq = (q & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[kq + e][row] = v[j][e];
+        } else {
+            const int krow = q >> 4, rq = (q & 15) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[krow][rq + e] = v[j][e];
         }
     }
 }
@@ -76,10 +91,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    float ra[2][4], rb[2][4];
+    tile_load<T, A_KMAJOR>(ra, A, a.amap, m0, a.M, kbeg, kend, a.vecA, tid);
+    tile_load<T, B_KMAJOR>(rb, B, a.bmap, n0, a.N, kbeg, kend, a.vecB, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage_tile<T, A_KMAJOR>(As, A, a.amap, m0, a.M, k0, kend, a.vecA, tid);
-        stage_tile<T, B_KMAJOR>(Bs, B, a.bmap, n0, a.N, k0, kend, a.vecB, tid);
+        tile_store<A_KMAJOR>(As, ra, tid);
+        tile_store<B_KMAJOR>(Bs, rb, tid);
         __syncthreads();
+        if (k0 + BK < kend) {      // next tile's loads fly during this tile's MFMAs
+            tile_load<T, A_KMAJOR>(ra, A, a.amap, m0, a.M, k0 + BK, kend, a.vecA, tid);
+            tile_load<T, B_KMAJOR>(rb, B, a.bmap, n0, a.N, k0 + BK, kend, a.vecB, tid);
+        }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const float av = As[2 * s + h][wr * 32 + i32];

@@ -454,9 +454,11 @@ __global__ __launch_bounds__(1024) void mmd_shift_kernel(const float* __restrict
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double s = 0.0;
-    if (c < DPAD)
+    if (c < DPAD) {
+#pragma unroll 4
         for (int w = ry; w < nwaves; w += 16)
             s += (double)colpart[(long long)w * DPAD + c] - (double)colpart[((long long)nwaves + w) * DPAD + c];
+    }
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && c < DPAD) {
@@ -551,8 +553,9 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan*
     // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
     const int wg_per_cu = p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1);
     const int slots = 256 * wg_per_cu;
-    const int max_cs = p->tiles_per_set >= 64 ? (p->tiles_per_set / 32 < 64 ? p->tiles_per_set / 32 : 64)
-                                              : (p->tiles_per_set >= 4 ? p->tiles_per_set / 4 : 1);
+    // at least 32 of the 2 * tiles_per_set column tiles per split (4 when the whole problem is tiny)
+    const int max_cs = p->tiles_per_set >= 32 ? (p->tiles_per_set / 16 < 64 ? p->tiles_per_set / 16 : 64)
+                                              : (p->tiles_per_set >= 4 ? p->tiles_per_set / 2 : 1);
     int cs = 1;
     double best = 1e30;
     for (int c = 1; c <= max_cs; ++c) {
@@ -563,7 +566,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan*
         if (waste <= 1.0005) break;
     }
     p->col_splits = cs < 1 ? 1 : cs;
-    int rpw = (p->n_pad + 2047) / 2048;
+    int rpw = (p->n_pad + 511) / 512;
     if (rpw < 4) rpw = 4;
     if (rpw > 64) rpw = 64;
     p->rows_per_wave = rpw;
