@@ -131,6 +131,29 @@ int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all,
                      void* d_z, double grad_scale,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Next to the path.
+ *
+ * Upsample of reconstructed_encoding into decoder memory.  Replaces
+ * transformers.models.funnel.modeling_funnel.upsample as called at transformer_vae/model.py:265-271:
+ *     stride == 1: identity;  otherwise repeat every token `stride` times along the sequence
+ *     (the first token is kept single when separate_cls; truncate_seq appends stride-1 zero rows)
+ *     and cut to target_len.
+ *   x (B, n, d) contiguous -> out (B, out_len, d), out_len = tvae_upsample_out_len(...) (host-only).
+ * Backward: d_x (B, n, d) = sum of d_out over the positions that copied each row. */
+int64_t tvae_upsample_out_len(int64_t n, int64_t stride, int64_t target_len, int separate_cls, int truncate_seq);
+int tvae_upsample_fwd(const void* x, void* out, int64_t B, int64_t n, int64_t d, int64_t stride,
+                      int64_t target_len, int separate_cls, int truncate_seq, int dtype, void* stream);
+int tvae_upsample_bwd(const void* d_out, void* d_x, int64_t B, int64_t n, int64_t d, int64_t stride,
+                      int64_t target_len, int separate_cls, int truncate_seq, int dtype, void* stream);
+
+/* Spherical interpolation of latent rows.  Replaces slerp, transformer_vae/utils.py:17-34 (callers:
+ * trainer.py:290,294,300):  out = sin((1-r)w)/sin(w) * t1 + sin(r w)/sin(w) * t2 with
+ * w = acos(<t1/|t1|, t2/|t2|>) per row.  t1, t2, out (rows, dim); `ratios` = per-row r on the device
+ * (fp32), or NULL to use the scalar `ratio`.  Forward only (its callers work on detached latents). */
+int tvae_slerp(const void* t1, const void* t2, const float* ratios, float ratio, void* out,
+               int64_t rows, int64_t dim, int dtype, void* stream);
+
 /* Measurement hook — no counterpart in the reference.  Arms the NEXT tvae_mmd_fwd_bwd call made
  * on this host thread: hipEventRecord(ev_start) / (ev_stop) are enqueued on that call's stream
  * immediately before / after the dominant kernel (mmd_tile_kernel), so bench.py can time that

@@ -237,6 +237,51 @@ def trainer_reduce(loss_per_replica, grad_accum_steps=1):
 
 
 # --------------------------------------------------------------------------- #
+# f1  upsample of reconstructed_encoding        model.py:265-271 (HF modeling_funnel.upsample)
+# f4  slerp of latent rows                      utils.py:17-34
+# --------------------------------------------------------------------------- #
+
+def upsample(x, stride, target_len, separate_cls=True, truncate_seq=False):
+    """Repeat tokens `stride` times along axis 1 (the first one stays single when separate_cls,
+    truncate_seq appends stride-1 zero rows before the cut) and keep target_len positions."""
+    if stride == 1:
+        return x
+    if separate_cls:
+        body = np.repeat(x[:, 1:], stride, axis=1)
+        if truncate_seq:
+            body = np.concatenate([body, np.zeros((x.shape[0], stride - 1, x.shape[2]), x.dtype)], axis=1)
+        return np.concatenate([x[:, :1], body[:, :max(target_len - 1, 0)]], axis=1)
+    return np.repeat(x, stride, axis=1)[:, :target_len]
+
+
+def upsample_backward(g, n, stride, target_len, separate_cls=True, truncate_seq=False):
+    """Adjoint of `upsample`: every input row collects the cotangents of its copies."""
+    if stride == 1:
+        return g
+    B, out_len, d = g.shape
+    dx = np.zeros((B, n, d), g.dtype)
+    for j in range(out_len):
+        if separate_cls:
+            src = 0 if j == 0 else 1 + (j - 1) // stride
+            if src > n - 1:
+                continue            # zero padding row
+        else:
+            src = j // stride
+        dx[:, src] += g[:, j]
+    return dx
+
+
+def slerp(ratio, t1, t2):
+    """sin((1-r)w)/sin(w) t1 + sin(r w)/sin(w) t2, w = acos(<t1/|t1|, t2/|t2|>) per row (utils.py:29-33)."""
+    lo = t1 / np.linalg.norm(t1, axis=1, keepdims=True)
+    hi = t2 / np.linalg.norm(t2, axis=1, keepdims=True)
+    omega = np.arccos((lo * hi).sum(1))
+    so = np.sin(omega)
+    ratio = np.asarray(ratio, dtype=t1.dtype)
+    return (np.sin((1.0 - ratio) * omega) / so)[:, None] * t1 + (np.sin(ratio * omega) / so)[:, None] * t2
+
+
+# --------------------------------------------------------------------------- #
 # synthetic inputs shared by tests, bench and golden generation (SURVEY.md 8d)
 # --------------------------------------------------------------------------- #
 

@@ -239,6 +239,40 @@ def main():
                         mmd_ref32=mmd32.numpy(), dz_f64=zt.grad.numpy())
     print("mmd_n1024_d77 mmd64=%.12e ref32=%.9e" % (float(mmd), float(mmd32)))
 
+    # ---- next-to-the-path rows: funnel upsample (model.py:265-271) and slerp (utils.py:17-34) ----
+    from transformers.models.funnel.modeling_funnel import upsample as hf_upsample
+    from transformer_vae.utils import slerp as ref_slerp
+    up = {}
+    rs = np.random.RandomState(31)
+    x = rs.standard_normal((3, 5, 24)).astype(np.float32)
+    g_up = {}
+    cases = [(2, 9, True, False), (4, 17, True, True), (4, 12, True, True), (2, 7, False, False), (3, 40, True, False),
+             (8, 16, False, False), (1, 5, True, False)]
+    for ci, (stride, tlen, sep, trunc) in enumerate(cases):
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        o = hf_upsample(xt, stride, tlen, sep, trunc)
+        cot = np.random.RandomState(40 + ci).standard_normal(tuple(o.shape))
+        (o * torch.from_numpy(cot)).sum().backward()
+        mine = orc.upsample(x.astype(np.float64), stride, tlen, sep, trunc)
+        assert mine.shape == tuple(o.shape) and np.array_equal(mine, o.detach().numpy())
+        assert np.allclose(orc.upsample_backward(cot, 5, stride, tlen, sep, trunc), xt.grad.numpy(), rtol=0, atol=1e-12)
+        up[f"case{ci}_args"] = np.array([stride, tlen, int(sep), int(trunc)], np.int64)
+        up[f"case{ci}_out"] = o.detach().numpy().astype(np.float32)
+        up[f"case{ci}_cot"] = cot.astype(np.float32)
+        up[f"case{ci}_dx"] = xt.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "upsample_cases.npz"), x=x, n_cases=np.int64(len(cases)), **up)
+    t1 = rs.standard_normal((22, 77)).astype(np.float32)
+    t2 = rs.standard_normal((22, 77)).astype(np.float32)
+    ratios = np.repeat(np.arange(0, 1.1, 0.1, dtype=np.float32), 2)                       # trainer.py:285,293
+    s_vec = ref_slerp(torch.from_numpy(ratios).double(), torch.from_numpy(t1).double(), torch.from_numpy(t2).double()).numpy()
+    s_sc = ref_slerp(0.3, torch.from_numpy(t1).double(), torch.from_numpy(t2).double()).numpy()
+    s32 = ref_slerp(torch.from_numpy(ratios), torch.from_numpy(t1), torch.from_numpy(t2)).numpy()
+    assert relerr(orc.slerp(ratios.astype(np.float64), t1.astype(np.float64), t2.astype(np.float64)), s_vec) < 1e-12
+    assert relerr(orc.slerp(0.3, t1.astype(np.float64), t2.astype(np.float64)), s_sc) < 1e-12
+    np.savez_compressed(os.path.join(HERE, "slerp_cases.npz"), t1=t1, t2=t2, ratios=ratios, out_vec_f64=s_vec,
+                        out_scalar03_f64=s_sc, out_vec_ref32=s32)
+    print("upsample + slerp fixtures written")
+
     # ---- loss-weight schedule (model.py:103-109) restated; a handful of known answers ----
     steps = np.array([0, 1000, 2500, 5000, 10000])
     w = np.array([float(torch.sigmoid(torch.tensor(s * 0.0025 - 6.25)).item()) for s in steps])

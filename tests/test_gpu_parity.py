@@ -246,3 +246,52 @@ def test_full_size_cfg3_properties():
     y = prior.double().cpu().numpy()
     ref = orc.mmd_gram(y, z) * n / B
     assert abs(float(out.reg_loss) - ref) <= F32_TOL * abs(ref)
+
+
+def test_upsample_matches_hf_vectors():
+    """the funnel upsample of reconstructed_encoding, forward and backward, fp32 + bf16."""
+    amd = _amd()
+    g = np.load(os.path.join(GOLD, "upsample_cases.npz"))
+    for ci in range(int(g["n_cases"])):
+        stride, tlen, sep, trunc = (int(v) for v in g[f"case{ci}_args"])
+        x = torch.from_numpy(g["x"]).to(dev()).requires_grad_(True)
+        out = amd.upsample(x, stride, tlen, bool(sep), bool(trunc))
+        assert tuple(out.shape) == g[f"case{ci}_out"].shape
+        assert np.array_equal(out.detach().cpu().numpy(), g[f"case{ci}_out"])          # pure copies: bit-exact
+        if stride > 1:
+            (out * torch.from_numpy(g[f"case{ci}_cot"]).to(dev())).sum().backward()
+            assert relerr(x.grad.cpu().numpy(), g[f"case{ci}_dx"]) <= F32_TOL
+        xb = torch.from_numpy(g["x"]).to(dev()).bfloat16()
+        ob = amd.upsample(xb, stride, tlen, bool(sep), bool(trunc))
+        ref = orc.upsample(xb.float().cpu().numpy(), stride, tlen, bool(sep), bool(trunc))
+        assert np.array_equal(ob.float().cpu().numpy(), ref)
+    # a decoder-memory sized case: properties (every output row is a copy of its source row; adjoint identity)
+    B, n, d, stride, tlen = 64, 30, 1024, 4, 117
+    x = torch.randn((B, n, d), device=dev(), requires_grad=True)
+    out = amd.upsample(x, stride, tlen, True, True)
+    assert out.shape == (B, tlen, d)
+    idx = torch.tensor([0] + [1 + (j - 1) // stride for j in range(1, tlen)], device=dev())
+    assert torch.equal(out.detach()[:, idx < n], x.detach()[:, idx[idx < n]])
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    lhs = float((out.detach() * w).sum())
+    rhs = float((x.detach() * x.grad).sum())
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+
+
+def test_slerp_matches_reference_vectors():
+    """slerp of latent rows with per-row and scalar ratios (trainer.py:290-300)."""
+    amd = _amd()
+    s = np.load(os.path.join(GOLD, "slerp_cases.npz"))
+    t1, t2 = torch.from_numpy(s["t1"]).to(dev()), torch.from_numpy(s["t2"]).to(dev())
+    out = amd.slerp(torch.from_numpy(s["ratios"]).to(dev()), t1, t2)
+    assert relerr(out.cpu().numpy(), s["out_vec_f64"]) <= F32_TOL
+    out = amd.slerp(0.3, t1, t2)
+    assert relerr(out.cpu().numpy(), s["out_scalar03_f64"]) <= F32_TOL
+    out = amd.slerp(torch.from_numpy(s["ratios"]).to(dev()), t1.bfloat16(), t2.bfloat16())
+    assert relerr(out.float().cpu().numpy(), s["out_vec_f64"]) <= BF16_TOL
+    # end points: ratio 0 -> t1, ratio 1 -> t2
+    assert relerr(amd.slerp(0.0, t1, t2).cpu().numpy(), s["t1"]) <= F32_TOL
+    assert relerr(amd.slerp(1.0, t1, t2).cpu().numpy(), s["t2"]) <= F32_TOL
+    with pytest.raises(RuntimeError):
+        amd.slerp(0.5, t1.cpu(), t2.cpu())

@@ -117,3 +117,19 @@ def test_modes_and_schedule():
         assert abs(orc.reg_loss_weight(int(step)) - w) <= 1e-6 * w
     assert orc.combine_loss(2.0, 0.5, 0.25) == 2.125
     assert orc.trainer_reduce([1.0, 3.0], 2) == 1.0
+
+
+def test_upsample_and_slerp_oracle_vs_reference_vectors():
+    """HF funnel upsample (model.py:265-271) and slerp (utils.py:17-34)."""
+    g = np.load(os.path.join(GOLD, "upsample_cases.npz"))
+    x = g["x"].astype(np.float64)
+    for ci in range(int(g["n_cases"])):
+        stride, tlen, sep, trunc = (int(v) for v in g[f"case{ci}_args"])
+        out = orc.upsample(x, stride, tlen, bool(sep), bool(trunc))
+        assert out.shape == g[f"case{ci}_out"].shape and np.array_equal(out.astype(np.float32), g[f"case{ci}_out"])
+        dx = orc.upsample_backward(g[f"case{ci}_cot"].astype(np.float64), x.shape[1], stride, tlen, bool(sep), bool(trunc))
+        assert relerr(dx, g[f"case{ci}_dx"]) < 1e-6
+    s = np.load(os.path.join(GOLD, "slerp_cases.npz"))
+    t1, t2 = s["t1"].astype(np.float64), s["t2"].astype(np.float64)
+    assert relerr(orc.slerp(s["ratios"].astype(np.float64), t1, t2), s["out_vec_f64"]) < 1e-12
+    assert relerr(orc.slerp(0.3, t1, t2), s["out_scalar03_f64"]) < 1e-12

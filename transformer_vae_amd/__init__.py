@@ -8,9 +8,10 @@ from .autoencoders import (EncoderDecoderVAE, LatentDecoder, LatentDecoderFunnel
                            LatentDecoderT5Norm, LatentEncoderLargeTanh, LatentEncoderNTokens, VAE_DECODER_MODELS,
                            VAE_ENCODER_MODELS)
 from .model_outputs import BaseVAE_Output
+from .utils import slerp, upsample
 
 build = _lib.build
 
 __all__ = ["EncoderDecoderVAE", "LatentEncoderNTokens", "LatentEncoderLargeTanh", "LatentDecoderNTokens",
            "LatentDecoderFunnelNorm", "LatentDecoderT5Norm", "LatentDecoder", "VAE_ENCODER_MODELS",
-           "VAE_DECODER_MODELS", "BaseVAE_Output", "build"]
+           "VAE_DECODER_MODELS", "BaseVAE_Output", "slerp", "upsample", "build"]

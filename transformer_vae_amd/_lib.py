@@ -38,6 +38,10 @@ SIGNATURES = {
                                _vp, _i64, _vp]),
     "tvae_mmd_workspace_bytes": (_i64, [_i64, _i64, _i64, _int]),
     "tvae_profile_next_mmd": (_int, [_vp, _vp]),
+    "tvae_upsample_out_len": (_i64, [_i64, _i64, _i64, _int, _int]),
+    "tvae_upsample_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _vp]),
+    "tvae_upsample_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _vp]),
+    "tvae_slerp": (_int, [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _int, _vp]),
     "tvae_mmd_fwd_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp, _i64, _vp]),
 }
 

@@ -202,6 +202,39 @@ class _MMDRegulariser(torch.autograd.Function):
         return g, None, None, None, None, None
 
 
+class _Upsample(torch.autograd.Function):
+    """HF funnel `upsample` as used on reconstructed_encoding (reference: model.py:265-271)."""
+
+    @staticmethod
+    def forward(ctx, x, stride: int, target_len: int, separate_cls: bool, truncate_seq: bool):
+        _require_device(x, "upsample")
+        if x.dim() != 3:
+            raise ValueError(f"upsample expects (batch, seq, hidden), got {tuple(x.shape)}")
+        dt = x.dtype if x.dtype in _DTYPES else torch.float32
+        xc = x.to(dt).contiguous()
+        B, n, d = xc.shape
+        lib = _lib.lib()
+        out_len = lib.tvae_upsample_out_len(n, stride, target_len, int(separate_cls), int(truncate_seq))
+        if out_len <= 0:
+            raise ValueError(f"upsample: empty output for n={n}, stride={stride}, target_len={target_len}")
+        out = torch.empty((B, out_len, d), dtype=dt, device=x.device)
+        if B * d > 0:
+            _lib.check(lib.tvae_upsample_fwd(_ptr(xc), _ptr(out), B, n, d, stride, target_len, int(separate_cls),
+                                             int(truncate_seq), _DTYPES[dt], _stream(xc)), "tvae_upsample_fwd")
+        ctx.meta = (B, n, d, stride, target_len, int(separate_cls), int(truncate_seq), dt, x.dtype)
+        return out if dt == x.dtype else out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, n, d, stride, target_len, sep, trunc, dt, x_dtype = ctx.meta
+        gc = g.to(dt).contiguous()
+        dx = torch.empty((B, n, d), dtype=dt, device=g.device)
+        if B * d > 0:
+            _lib.check(_lib.lib().tvae_upsample_bwd(_ptr(gc), _ptr(dx), B, n, d, stride, target_len, sep, trunc,
+                                                    _DTYPES[dt], _stream(gc)), "tvae_upsample_bwd")
+        return (dx if dt == x_dtype else dx.to(x_dtype)), None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------
 # functional API used by the modules in autoencoders.py
 # ------------------------------------------------------------------------------------------
@@ -233,3 +266,33 @@ def mmd_reg_loss(latent2d, prior, batch_size: int, n_latents: int):
 def mmd_row_block(z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float):
     """Row-sharded building block: returns (local loss share, float64[3] partial sums)."""
     return _MMDRegulariser.apply(z_rows, z_all, y_all, int(row_offset), float(loss_scale), float(grad_scale))
+
+
+def upsample(x, stride: int, target_len: int, separate_cls: bool = True, truncate_seq: bool = False):
+    """Drop-in for transformers.models.funnel.modeling_funnel.upsample (model.py:10, 265-271)."""
+    if stride == 1:
+        return x
+    return _Upsample.apply(x, int(stride), int(target_len), bool(separate_cls), bool(truncate_seq))
+
+
+def slerp(ratio, t1, t2):
+    """Drop-in for transformer_vae.utils.slerp (utils.py:17-34): `ratio` is a float or a (rows,) tensor;
+    t1, t2 are (rows, dim).  Forward only — the result carries no autograd graph."""
+    _require_device(t1, "slerp")
+    if t1.dim() != 2 or t1.shape != t2.shape:
+        raise ValueError(f"slerp expects two (rows, dim) tensors of equal shape, got {tuple(t1.shape)} and {tuple(t2.shape)}")
+    dt = t1.dtype if t1.dtype in _DTYPES else torch.float32
+    a, b = t1.detach().to(dt).contiguous(), t2.detach().to(dt).contiguous()
+    rows, dim = a.shape
+    out = torch.empty_like(a)
+    if torch.is_tensor(ratio) and ratio.numel() > 1:
+        if ratio.numel() != rows:
+            raise ValueError(f"slerp: {ratio.numel()} ratios for {rows} rows")
+        r = ratio.detach().to(device=a.device, dtype=torch.float32).reshape(-1).contiguous()
+        rp, rs = _ptr(r), 0.0
+    else:
+        rp, rs = None, float(ratio)
+    if rows > 0:
+        _lib.check(_lib.lib().tvae_slerp(_ptr(a), _ptr(b), rp, rs, _ptr(out), rows, dim, _DTYPES[dt], _stream(a)),
+                   "tvae_slerp")
+    return out if dt == t1.dtype else out.to(t1.dtype)
