@@ -76,3 +76,23 @@ def test_oracle_is_not_imported_by_the_product():
     for mod in (amd._lib, amd.autoencoders, amd.functional, amd.distributed if hasattr(amd, "distributed") else amd):
         src = inspect.getsource(mod)
         assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_reg_weight_schedule_and_deferred_logs():
+    import os
+    import numpy as np
+    from transformer_vae_amd import losses
+    s = np.load(os.path.join(os.path.dirname(__file__), "golden", "reg_weight_schedule.npz"))
+    for step, w in zip(s["steps"], s["w"]):                      # values from the reference's torch.sigmoid(...).item()
+        assert abs(losses.regulariser_loss_weight(int(step)) - float(w)) <= 1e-6 * float(w)
+    assert losses.regulariser_loss_weight(None) == 0 and losses.regulariser_loss_weight(10, use_reg_loss=False) == 0
+    assert float(losses.combine_loss(torch.tensor(2.0), torch.tensor(0.5), 0.25)) == 2.125
+    # same numbers as the reference's _update_logs/get_latest_logs bookkeeping (model.py:111-134)
+    logs = losses.DeferredLogs()
+    assert logs.get_latest_logs() == {}
+    logs.update(decoder_ce=torch.tensor(2.0), reg_loss=torch.tensor(0.5), reg_loss_w=0.1)
+    logs.update(decoder_ce=torch.tensor(4.0), reg_loss=torch.tensor(1.5), reg_loss_w=0.3)
+    out = logs.get_latest_logs()
+    assert out == pytest.approx({"decoder_ce": 3.0, "reg_loss": 1.0, "reg_loss_w": 0.2})
+    logs.update(decoder_ce=torch.tensor(1.0), reg_loss=torch.tensor(0.0), reg_loss_w=0.5)
+    assert logs.get_latest_logs() == pytest.approx({"decoder_ce": 1.0, "reg_loss": 0.0, "reg_loss_w": 0.5})
