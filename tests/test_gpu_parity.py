@@ -295,3 +295,69 @@ def test_slerp_matches_reference_vectors():
     assert relerr(amd.slerp(1.0, t1, t2).cpu().numpy(), s["t2"]) <= F32_TOL
     with pytest.raises(RuntimeError):
         amd.slerp(0.5, t1.cpu(), t2.cpu())
+
+
+def test_trainer_step_and_interpolation_inputs():
+    """SURVEY 8f row f3/f4: training_step -> get_loss_grad (trainer.py:258-281,378-401) drives the fused path;
+    gradual_interpolation_inputs (trainer.py:283-295) against the slerp oracle."""
+    amd = _amd()
+    from transformer_vae_amd import losses, trainer as T
+    B, S, d, n, L = 6, 9, 32, 3, 11
+    h, params, prior, g0 = orc.synth_inputs(B, S, d, n, L, 10, "")
+    vae = build_vae(d, L, n, "", params)
+    prior_t, g0_t = torch.from_numpy(prior).to(dev()), torch.from_numpy(g0).to(dev())
+
+    class Wrapper(torch.nn.Module):          # stands in for Funnel_T5_VAE_Model.forward's loss combine (model.py:305-306)
+        def __init__(self, vae):
+            super().__init__()
+            self.vae = vae
+
+        def forward(self, input_encoding):
+            out = self.vae(input_encoding=input_encoding, true_samples=prior_t)
+            ce = (out.reconstructed_encoding * g0_t).sum()
+            return {"loss": losses.combine_loss(ce, out.reg_loss, 0.5)}
+
+    model = Wrapper(vae)
+    ht = torch.from_numpy(h).to(dev()).requires_grad_(True)
+    loss = T.training_step(model, {"input_encoding": ht}, gradient_accumulation_steps=2)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    fwd = orc.bottleneck_forward(h.astype(np.float64), p64, n, prior.astype(np.float64), 1e-9)
+    bwd = orc.bottleneck_backward(h.astype(np.float64), p64, n, fwd, g0.astype(np.float64), 0.5, prior.astype(np.float64))
+    ref_loss = 0.5 * ((fwd["recon"] * g0).sum() + 0.5 * fwd["reg_loss"])
+    assert abs(float(loss) - ref_loss) <= F32_TOL * max(abs(ref_loss), 1e-3) and not loss.requires_grad
+    assert relerr(ht.grad.cpu().numpy(), 0.5 * bwd["h"]) <= F32_TOL
+    assert relerr(vae.encoder.token_to_latent.weight.grad.cpu().numpy(), 0.5 * bwd["We"]) <= F32_TOL
+
+    rs = np.random.RandomState(5)
+    a, b = rs.standard_normal((n, L)).astype(np.float32), rs.standard_normal((n, L)).astype(np.float32)
+    ratios = np.arange(0, 1.1, 0.1, dtype=np.float32)
+    out, r = T.gradual_interpolation_inputs(torch.from_numpy(a).to(dev()), torch.from_numpy(b).to(dev()))
+    assert out.shape == (11, n, L) and np.allclose(r.cpu().numpy(), ratios)
+    rep = np.repeat(ratios, n)
+    ref = orc.slerp(rep.astype(np.float64), np.tile(a, (11, 1)).astype(np.float64), np.tile(b, (11, 1)).astype(np.float64))
+    assert relerr(out.reshape(-1, L).cpu().numpy(), ref) <= F32_TOL
+    out1, _ = T.gradual_interpolation_inputs(torch.from_numpy(a).to(dev()), torch.from_numpy(b).to(dev()),
+                                             interpolate_all_at_once=True)
+    ref1 = orc.slerp(ratios.astype(np.float64), np.tile(a.reshape(1, -1), (11, 1)).astype(np.float64),
+                     np.tile(b.reshape(1, -1), (11, 1)).astype(np.float64))
+    assert relerr(out1.reshape(11, -1).cpu().numpy(), ref1) <= F32_TOL
+    lat = torch.from_numpy(rs.standard_normal((4, n, L)).astype(np.float32)).to(dev())
+    mixed, rr = T.random_interpolation_inputs(lat)
+    assert mixed.shape == lat.shape and float(rr.min()) >= 0 and float(rr.max()) <= 0.5
+
+
+@pytest.mark.parametrize("N,D", [(1100, 256), (1536, 300), (1000, 640), (2000, 768), (1040, 1024)])
+def test_mmd_bf16_wide_latents_vs_oracle(N, D):
+    """bf16 latents and priors at the wide shapes: loss and gradient against the fp64 oracle evaluated on the
+    SAME bf16-rounded values (so the tolerance covers the arithmetic, not the input rounding)."""
+    from transformer_vae_amd import functional as F
+    rs = np.random.RandomState(N + D)
+    zt = torch.from_numpy(np.tanh(rs.standard_normal((N, D))).astype(np.float32)).to(dev()).bfloat16().requires_grad_(True)
+    yt = torch.from_numpy(rs.standard_normal((N, D)).astype(np.float32)).to(dev()).bfloat16()
+    reg = F.mmd_reg_loss(zt, yt, batch_size=1, n_latents=1)
+    reg.backward()
+    z64, y64 = zt.detach().double().cpu().numpy(), yt.double().cpu().numpy()
+    ref = orc.mmd_gram(y64, z64)
+    gref = orc.mmd_grad_latent_rows(z64, z64, y64)
+    assert abs(float(reg) - ref) <= BF16_TOL * abs(ref), (float(reg), ref)
+    assert relerr(zt.grad.float().cpu().numpy(), gref) <= BF16_TOL

@@ -96,3 +96,45 @@ def test_reg_weight_schedule_and_deferred_logs():
     assert out == pytest.approx({"decoder_ce": 3.0, "reg_loss": 1.0, "reg_loss_w": 0.2})
     logs.update(decoder_ce=torch.tensor(1.0), reg_loss=torch.tensor(0.0), reg_loss_w=0.5)
     assert logs.get_latest_logs() == pytest.approx({"decoder_ce": 1.0, "reg_loss": 0.0, "reg_loss_w": 0.5})
+
+
+def test_trainer_arguments_and_loss_grad():
+    """the MMD scope surfaces through the reference's argument system (train.py:33-100)
+    and `get_loss_grad` keeps the reference's reduction order (trainer.py:258-281)."""
+    from dataclasses import dataclass, fields
+    from transformer_vae_amd import trainer as T
+
+    @dataclass
+    class FakeTrainingArguments:          # stands in for VAE_TrainingArguments (HF TrainingArguments subclass)
+        save_steps: int = 1000
+        interpolate_all_at_once: bool = False
+
+    Args = T.extend_training_arguments(FakeTrainingArguments, "VAE_TrainingArguments")
+    assert {f.name for f in fields(Args)} == {"save_steps", "interpolate_all_at_once", "mmd_scope",
+                                              "mmd_compensate_ddp_mean"}
+    a = Args()
+    assert a.mmd_scope == "local" and a.mmd_compensate_ddp_mean is True and a.save_steps == 1000
+    a.validate_mmd()
+    with pytest.raises(ValueError, match="Unknown `mmd_scope`"):
+        Args(mmd_scope="planet").validate_mmd()
+    from transformers import HfArgumentParser
+    parsed, = HfArgumentParser(Args).parse_args_into_dataclasses(["--mmd_scope", "global", "--save_steps", "5"])
+    assert parsed.mmd_scope == "global" and parsed.save_steps == 5
+
+    c = cfg()
+    vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](c), amd.VAE_DECODER_MODELS[""](c))
+    T.configure_vae(vae, parsed, process_group="pg")
+    assert vae.mmd_scope == "global" and vae.process_group == "pg" and vae.compensate_ddp_mean is True
+    with pytest.raises(ValueError):
+        T.configure_vae(vae, SimpleNamespace(mmd_scope="nope"))
+
+    # reduction order of trainer.py:265-281: mean over replicas, / accumulation steps, backward, detached result
+    w = torch.tensor([1.0, 3.0], requires_grad=True)
+    out = T.get_loss_grad(w * 2.0, n_gpu=2, gradient_accumulation_steps=4)
+    assert float(out) == 1.0 and not out.requires_grad
+    assert torch.allclose(w.grad, torch.tensor([0.25, 0.25]))
+    seen = []
+    w2 = torch.tensor(2.0, requires_grad=True)
+    T.get_loss_grad(w2 * 3.0, backward=lambda l: (seen.append(float(l)), l.backward()))
+    assert seen == [6.0] and float(w2.grad) == 3.0
+    assert T.get_loss({"loss": 7}) == 7 and T.get_loss((9, 1)) == 9

@@ -9,9 +9,10 @@ from .autoencoders import (EncoderDecoderVAE, LatentDecoder, LatentDecoderFunnel
                            VAE_ENCODER_MODELS)
 from .model_outputs import BaseVAE_Output
 from .utils import slerp, upsample
+from . import losses, trainer
 
 build = _lib.build
 
 __all__ = ["EncoderDecoderVAE", "LatentEncoderNTokens", "LatentEncoderLargeTanh", "LatentDecoderNTokens",
            "LatentDecoderFunnelNorm", "LatentDecoderT5Norm", "LatentDecoder", "VAE_ENCODER_MODELS",
-           "VAE_DECODER_MODELS", "BaseVAE_Output", "slerp", "upsample", "build"]
+           "VAE_DECODER_MODELS", "BaseVAE_Output", "slerp", "upsample", "losses", "trainer", "build"]
