@@ -37,6 +37,7 @@ CONFIGS = {
     "cfg5": (65536, 1, 1024, 1, 1024, 5, "configs[4] MMD stress global batch 65536 latent dim 1024"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= vector fp32 peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 dense MFMA peak (~2.5 PFLOP/s)
 REG_W = 0.5
 
 
@@ -66,13 +67,13 @@ class HipEvents:
         return out
 
 
-def make_vae(d, L, n, device, dtype, scope, world):
+def make_vae(d, L, n, device, dtype, scope, world, mmd_dtype=None):
     import transformer_vae_amd as amd
     cfg = SimpleNamespace(t5=SimpleNamespace(d_model=d), funnel=SimpleNamespace(d_model=d, layer_norm_eps=1e-9),
                           latent_size=L, n_latent_tokens=n)
     torch.manual_seed(0)      # default nn.Linear / LayerNorm init under seed 0
     vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](cfg), amd.VAE_DECODER_MODELS[""](cfg), True,
-                                mmd_scope=scope, compensate_ddp_mean=False)
+                                mmd_scope=scope, compensate_ddp_mean=False, mmd_dtype=mmd_dtype)
     return vae.to(device).to(dtype)
 
 
@@ -136,6 +137,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--mmd-dtype", default="ref", choices=["ref", "bf16"],
+                    help="ref: the reference's promotion (fp32 against its fp32 prior); bf16: opt-in bf16 matrix-core MMD")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -166,7 +169,9 @@ def main():
 
     from transformer_vae_amd import _lib
     lib = _lib.lib()
-    vae = make_vae(d, L, n, device, dtype, "global" if world > 1 else "local", world)
+    mmd_bf16 = args.mmd_dtype == "bf16"
+    vae = make_vae(d, L, n, device, dtype, "global" if world > 1 else "local", world,
+                   torch.bfloat16 if mmd_bf16 else None)
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + cfg_id + 1000 * rank)
     h = torch.randn((Bl, S, d), generator=gen, device=device, dtype=torch.float32).to(dtype).requires_grad_(True)
@@ -229,16 +234,21 @@ def main():
             traffic = json.load(open(tfile)).get(f"{args.config}_{args.dtype}_gpus{world}")
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
-                "kernel": "mmd_tile_kernel", "kernel_ms": kern_ms, "launches_timed": len(tile_ms),
-                "peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak; the Gram and gradient products run in exact fp32"}
+    bf16_tiles = mmd_bf16 and L > 192
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16_tiles else PEAK_F32_MFMA_TFLOPS
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": (achieved / peak) if achieved else None, "traffic": None if mmd_bf16 else traffic,
+                "kernel": "mmd_bf16_kernel" if bf16_tiles else "mmd_tile_kernel", "kernel_ms": kern_ms,
+                "launches_timed": len(tile_ms),
+                "peak_note": ("bf16 MFMA (v_mfma_f32_16x16x32_bf16) dense peak; opt-in mode, latents and prior rounded to bf16"
+                              if bf16_tiles else
+                              "fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak; the Gram and gradient products run in exact fp32")}
 
     line = {
         "metric": "bottleneck+MMD fwd+bwd samples/sec", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "dtype": ("f32" if args.dtype == "fp32" else "bf16") + ("+bf16-mmd" if mmd_bf16 else ""), "data": "synthetic",
         "config": {"workload": f"{args.config}: {label}", "global_batch": B, "seq_len": S, "d_model": d,
                    "n_latent_tokens": n, "latent_size": L, "mmd_rows": N,
                    "parallelism": f"row-sharded global-batch MMD x{world}" if world > 1 else "single GPU"},

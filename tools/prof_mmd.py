@@ -2,7 +2,8 @@
 """Run the MMD entry point alone a few times (for rocprofv3 --kernel-trace / --pmc passes).
 
     python tools/prof_mmd.py N D [iters] [rows]
-`rows` < N profiles a row block (what one rank of a sharded run executes)."""
+`rows` < N profiles a row block (what one rank of a sharded run executes).
+TVAE_PROF_DTYPE=bf16 feeds bf16 latents/priors; the script prints the wall time of the last iteration."""
 import os
 import sys
 
@@ -18,9 +19,16 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 z = torch.tanh(torch.randn((N, D), generator=g, device=dev))
 y = torch.randn((N, D), generator=g, device=dev)
+if os.environ.get("TVAE_PROF_DTYPE", "fp32") == "bf16":
+    z, y = z.bfloat16(), y.bfloat16()
+import time  # noqa: E402
 ls, gs = F.mmd_scales(max(1, N // 30), 30, N, D)
 for _ in range(iters):
     zr = z[:rows].clone().requires_grad_(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     loss, sums = F.mmd_row_block(zr, z, y, 0, ls, gs)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print("last iteration %.3f ms -> %.1f TFLOP/s algorithmic" % (dt * 1e3, 10.0 * rows * N * D / dt / 1e12))
 print("loss", float(loss), "sums", sums.tolist())

@@ -123,10 +123,16 @@ class EncoderDecoderVAE(nn.Module):
     batch_size = None
 
     def __init__(self, encoder, decoder, use_reg_loss=True, mmd_scope="local", process_group=None,
-                 compensate_ddp_mean=False):
+                 compensate_ddp_mean=False, mmd_dtype=None):
         super().__init__()
         if mmd_scope not in ("local", "global"):
             raise ValueError(f"mmd_scope must be 'local' or 'global', got {mmd_scope!r}")
+        if mmd_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError(f"mmd_dtype must be None, torch.float32 or torch.bfloat16, got {mmd_dtype!r}")
+        # None: the reference's promotion (bf16 latents against its always-fp32 prior run in fp32).
+        # torch.bfloat16 (opt-in): latents and prior are rounded to bf16 and the regulariser runs on the bf16
+        # matrix cores (fp32 accumulation, fp32 loss; gradient rounded to bf16) for latent sizes > 192.
+        self.mmd_dtype = mmd_dtype
         self.encoder = encoder
         self.decoder = decoder
         self.use_reg_loss = use_reg_loss
@@ -169,6 +175,8 @@ class EncoderDecoderVAE(nn.Module):
             true_samples = true_samples.reshape(latent.shape).to(latent.device)
         if latent.numel() == 0:
             return torch.zeros((), dtype=torch.float32, device=latent.device)
+        if self.mmd_dtype is not None:
+            latent, true_samples = latent.to(self.mmd_dtype), true_samples.to(self.mmd_dtype)
         if self.mmd_scope == "global":
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:

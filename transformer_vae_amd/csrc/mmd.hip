@@ -405,11 +405,306 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
     }
 }
 
-// ---- prep: fp32 zero-padded copies (row stride DPAD), squared norms, per-wave column sums ----
-template <typename T>
+// =======================================================================================
+// bf16 latents, wide dimension (DPAD = 128 KB, KB = 2..8): the same algorithm on the 16x bf16 matrix cores.
+//
+// One workgroup = 4 waves owns 32 rows (two 16-row tiles t) and walks 32-point steps (two 16-point
+// tiles pt); the feature dimension is sliced over the waves in KB blocks of 32 (one
+// v_mfma_f32_16x16x32_bf16 k-step each).  Differences from the fp32 kernel:
+//   * the four partial S' tiles (pt, t) are REDUCE-SCATTERED: wave w finishes tile (pt = w>>1, t = w&1)
+//     only (three remote partials), so the expm1 work is split over the waves instead of replicated;
+//   * E (signed) is rounded to bf16 and shared through a 2 KiB LDS buffer laid out so that every wave
+//     reads back, with one ds_read_b128 per row tile, exactly its B operand of the gradient MFMA
+//     (k = 8g + j  <->  point tile j>>2, point 4g + (j&3));
+//   * the gradient's A operand X^T comes from the SAME LDS image through ds_read_b64_tr_b16.
+// LDS image of a wave's slice (32 points x SW bf16): DMA instruction 2 s + a carries features
+// [32 s, 32 s + 32) of points [16 a, 16 a + 16) = 64 chunks of 16 B; lane l fetches chunk
+// c = (l & 3) ^ 2 ((l >> 4) & 1) of point rr = l >> 2, so every point contributes 64 contiguous bytes per
+// instruction (16 half cache lines per wave-instruction; a 32-B-per-point variant touched 32 lines and ran
+// at a fifth of the matrix-core rate), and chunk (rr, c) sits at position 4 rr + (c ^ 2 ((rr >> 2) & 1)):
+// the Gram row read (ds_read_b128) and the transposed gradient read are both bank-conflict free, each
+// instruction's 1 KiB is contiguous (in-place refill as in the fp32 kernel) and all instructions share one
+// per-lane source offset.
+// Sums and row sums use the fp32 E; only the gradient product sees the bf16 rounding of E (2^-9).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+constexpr int STEP_P = 32;
+
+template <int KB, bool GRAD>
+struct Bf16Lds {
+    static constexpr int SW = 32 * KB;                       // bf16 features per wave
+    static constexpr int SLICE_B = STEP_P * SW * 2;          // bytes of one wave's slice of a 32-point step
+    static constexpr int NORM_B = 4 * SLICE_B;               // [2 buf][4 waves][32] float point norms
+    static constexpr int XCH_B = NORM_B + 2 * 4 * STEP_P * 4;
+    static constexpr int XCH_ONE_B = 12 * 64 * 16;           // [dst tile][3 remote sources][64 lanes] float4
+    // the gradient instantiation has a second barrier per step, which also protects a single exchange buffer
+    static constexpr int XBUFS = GRAD ? 1 : (KB <= 6 ? 2 : 1);
+    static constexpr int EBUF_B = XCH_B + XBUFS * XCH_ONE_B; // [2 row tiles][64 lanes][2 point tiles] 4 x bf16
+    static constexpr int BYTES = EBUF_B + (GRAD ? 2 * 64 * 16 : 0);
+    static_assert(BYTES <= 160 * 1024, "bf16 tile kernel exceeds the 160 KiB LDS");
+    static_assert(XCH_ONE_B >= 4 * 18 * 8, "final reduction reuses the exchange buffer");
+};
+
+template <int KB, bool GRAD>
+__global__ __launch_bounds__(256, (KB <= 6 ? 2 : 1)) void mmd_bf16_kernel(MmdArgs a) {
+    using L = Bf16Lds<KB, GRAD>;
+    constexpr int SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;     // NI: DMA instructions = 16-feature blocks per slice
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sm = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned xs_byte = smem_byte + (unsigned)(wave * L::SLICE_B);
+    const char* xs = sm + wave * L::SLICE_B;
+    const int my_pt = wave >> 1, my_t = wave & 1;             // the S' tile this wave finishes
+
+    const int per_problem = a.row_blocks * a.col_splits;
+    const int bid = a.problem_base * per_problem + blockIdx.x;
+    const int problem = GRAD ? 0 : bid / per_problem;
+    const int rem = bid - problem * per_problem;
+    const int rb = rem / a.col_splits, sp = rem - rb * a.col_splits;
+    const int i0 = rb * ROWS_PER_WG;
+
+    // ---- the 32 rows of this workgroup: this wave's feature slice, in registers as MFMA B operands ----
+    const bf16* rows = reinterpret_cast<const bf16*>(a.cols[problem]) + (long long)a.row_offset * DPAD;
+    const float* rnorm = a.cnorm[problem] + a.row_offset;
+    bf16x8_t zreg[2][KB];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = i0 + 16 * t + i16;
+        const bf16* zp = rows + (long long)row * DPAD + wave * SW + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KB; ++s) {
+            if (row < a.n_rows) zreg[t][s] = *reinterpret_cast<const bf16x8_t*>(zp + 32 * s);
+            else zreg[t][s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    const int my_row = i0 + 16 * my_t + i16;
+    const bool my_valid = my_row < a.n_rows;
+    float rn = my_valid ? rnorm[my_row] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < KB; ++s) asm volatile("" : "+v"(zreg[t][s]));
+    asm volatile("" : "+v"(rn));
+
+    f32x4 acc[GRAD ? NI : 1][2];
+    if (GRAD) {
+#pragma unroll
+        for (int db = 0; db < NI; ++db) {
+            acc[db][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[db][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // 32-point steps; the symmetric y-y enumeration is the fp32 kernel's (one step = one block J)
+    const int nJ = a.tiles_per_set >> 1;
+    const bool sym = !GRAD && problem == 1 && a.sym;
+    const int blkI = (a.row_offset >> 5) + rb;
+    const int symA = (blkI + 1) >> 1;
+    const int symM = symA + 1 + ((nJ - 1 - blkI) >> 1);
+    const long long total = problem == 0 ? 2ll * nJ : (sym ? (long long)symM : (long long)nJ);
+    const long long base = (problem == 0 || sym) ? 0 : nJ;
+    const int sb = (int)(base + sp * total / a.col_splits);
+    const int se = (int)(base + (sp + 1) * total / a.col_splits);
+    auto actual = [&](int v) -> int {
+        if (!sym) return v;
+        const int J = v < symA ? ((blkI + 1) & 1) + 2 * v : (v == symA ? blkI : blkI + 2 * (v - symA));
+        return nJ + J;
+    };
+
+    // per-lane constants of the LDS image
+    const int dma_r = lane >> 2, dma_c = (lane & 3) ^ (2 * ((lane >> 4) & 1));
+    const unsigned dma_voff = (unsigned)(dma_r * DPAD + 8 * dma_c) * 2u;
+    const int gram_off = 16 * (4 * i16 + (g ^ (2 * ((i16 >> 2) & 1))));            // + 1024 (2 s + pt)
+    const int tq = i16 >> 2, tp = i16 & 3;
+    // transposed read of 16-feature block db of point tile pt: + 1024 (2 (db >> 1) + pt), base by parity of db
+    const int tr_off0 = 16 * (4 * (4 * g + tq) + 2 * (g & 1) + (tp >> 1)) + 8 * (tp & 1);
+    const int tr_off1 = 16 * (4 * (4 * g + tq) + 2 * ((g & 1) ^ 1) + (tp >> 1)) + 8 * (tp & 1);
+    auto tr_read = [&](int byte_off) -> s16x4_t {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(__attribute__((address_space(3))) char*)(sm + byte_off));
+    };
+
+    auto step_src = [&](int v) -> const bf16* {
+        const int u = actual(v);
+        const int set = u >= nJ ? 1 : 0;
+        const int p0 = (u - set * nJ) * STEP_P;
+        return reinterpret_cast<const bf16*>(a.cols[set]) + (long long)p0 * DPAD + wave * SW;
+    };
+    auto stage_norms = [&](int v, int nbuf) {
+        const int u = actual(v);
+        const int set = u >= nJ ? 1 : 0;
+        const int p0 = (u - set * nJ) * STEP_P;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            smem_byte + (unsigned)(L::NORM_B + (nbuf * 4 + wave) * STEP_P * 4));
+        const float* src = uniform_ptr(a.cnorm[set] + p0);
+        if (lane < STEP_P) dma4(src, (unsigned)lane * 4u, dst);
+    };
+    auto dma_block = [&](const bf16* X, int i) {      // i = 2 s + a
+        dma16(reinterpret_cast<const float*>(X + (long long)(16 * (i & 1)) * DPAD + 32 * (i >> 1)), dma_voff,
+              xs_byte + 1024u * i);
+    };
+
+    double sum0 = 0.0, sum1 = 0.0, rowsum = 0.0;
+
+    // DMA issue order: norms(k) ... X(k) blocks 0..NI-1 ...; norms(k+1) at the top of iteration k
+    if (sb < se) {
+        stage_norms(sb, 0);
+        const bf16* X0 = step_src(sb);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) dma_block(X0, i);
+    }
+    for (int step = sb; step < se; ++step) {
+        const int u = actual(step);
+        const int set = u >= nJ ? 1 : 0;
+        const int p0 = (u - set * nJ) * STEP_P;
+        const float wsym = (sym && (p0 >> 5) != blkI) ? 2.f : 1.f;
+        const int buf = (step - sb) & 1;
+        const bool has_next = step + 1 < se;
+        const bf16* Xn = step_src(has_next ? step + 1 : step);
+        if (has_next) stage_norms(step + 1, buf ^ 1);
+        else wait_vmcnt<0>();
+
+        // 1. partial Gram over the slice: S[pt][t] (16 points x 16 rows each)
+        f32x4 S00 = {0.f, 0.f, 0.f, 0.f}, S01 = S00, S10 = S00, S11 = S00;
+        wait_vmcnt<NI - 1>();
+        bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xs + gram_off);
+        bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 1024);
+#pragma unroll
+        for (int s = 0; s < KB; ++s) {
+            bf16x8_t n0 = a0, n1 = a1;
+            if (s + 1 < KB) {
+                wait_vmcnt_n(GRAD ? NI - 2 * (s + 1) - 1 : NI - 3);
+                n0 = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + 1));
+                n1 = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + 1) + 1024);
+            }
+            S00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, zreg[0][s], S00, 0, 0, 0);
+            S01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, zreg[1][s], S01, 0, 0, 0);
+            S10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, zreg[0][s], S10, 0, 0, 0);
+            S11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, zreg[1][s], S11, 0, 0, 0);
+            if (!GRAD) {
+                asm volatile("" ::"v"(S00), "v"(S01), "v"(S10), "v"(S11));
+                if (has_next) { dma_block(Xn, 2 * s); dma_block(Xn, 2 * s + 1); }
+            }
+            a0 = n0; a1 = n1;
+        }
+
+        // 2. reduce-scatter of the partials: tile q4 = 2 pt + t goes to wave q4
+        f32x4* xb = reinterpret_cast<f32x4*>(sm + L::XCH_B + (L::XBUFS == 2 ? buf * L::XCH_ONE_B : 0));
+        if (wave != 0) xb[(0 * 3 + ((wave - 0 - 1) & 3)) * 64 + lane] = S00;
+        if (wave != 1) xb[(1 * 3 + ((wave - 1 - 1) & 3)) * 64 + lane] = S01;
+        if (wave != 2) xb[(2 * 3 + ((wave - 2 - 1) & 3)) * 64 + lane] = S10;
+        if (wave != 3) xb[(3 * 3 + ((wave - 3 - 1) & 3)) * 64 + lane] = S11;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        f32x4 sv = wave == 0 ? S00 : (wave == 1 ? S01 : (wave == 2 ? S10 : S11));
+        sv += xb[(wave * 3 + 0) * 64 + lane];
+        sv += xb[(wave * 3 + 1) * 64 + lane];
+        sv += xb[(wave * 3 + 2) * 64 + lane];
+        if (!GRAD && L::XBUFS == 1) {       // single exchange buffer without the E barrier: fence the reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+
+        // 3. E = expm1(-t) for this wave's tile; register r <-> point p0 + 16 pt + 4 g + r, column = row i16
+        const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_B + ((buf * 4 + wave) * STEP_P + 16 * my_pt + 4 * g) * 4);
+        f32x4 tt, e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            tt[r] = fmaxf((cn[r] + rn - 2.f * sv[r]) * a.inv_d2, 0.f);
+            e[r] = em1_neg(tt[r]);
+        }
+        if (__any(fmaxf(fmaxf(tt[0], tt[1]), fmaxf(tt[2], tt[3])) >= 0.125f)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (tt[r] >= 0.125f) e[r] = expm1f(-tt[r]);
+        }
+        if (!my_valid) e = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p0 + STEP_P > a.n_cols) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (p0 + 16 * my_pt + 4 * g + r >= a.n_cols) e[r] = 0.f;
+        }
+        const float es = (e[0] + e[1]) + (e[2] + e[3]);
+        if (set) { sum1 += (double)(wsym * es); rowsum -= (double)es; }
+        else { sum0 += (double)es; rowsum += (double)es; }
+
+        // 4. gradient: acc^T[d][i] += X^T[d][p] (s_p E[p][i]) over the 32 points of the step in ONE k-step
+        if (GRAD) {
+            if (set) e = -e;
+            bf16x4_t eb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eb[r] = (__bf16)e[r];
+            bf16x4_t* ebuf = reinterpret_cast<bf16x4_t*>(sm + L::EBUF_B);
+            ebuf[(my_t * 64 + lane) * 2 + my_pt] = eb;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bf16x8_t E0 = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (0 * 64 + lane) * 16);
+            const bf16x8_t E1 = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (1 * 64 + lane) * 16);
+            const int tb0 = wave * L::SLICE_B + tr_off0, tb1 = wave * L::SLICE_B + tr_off1;
+            s16x4_t ga0 = tr_read(tb0), ga1 = tr_read(tb0 + 1024);
+#pragma unroll
+            for (int db = 0; db < NI; ++db) {
+                s16x4_t gn0 = ga0, gn1 = ga1;
+                if (db + 1 < NI) {
+                    const int nb = (((db + 1) & 1) ? tb1 : tb0) + 2048 * ((db + 1) >> 1);
+                    gn0 = tr_read(nb);
+                    gn1 = tr_read(nb + 1024);
+                }
+                const s16x8_t av = __builtin_shufflevector(ga0, ga1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t ab = __builtin_bit_cast(bf16x8_t, av);
+                acc[db][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, E0, acc[db][0], 0, 0, 0);
+                acc[db][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, E1, acc[db][1], 0, 0, 0);
+                asm volatile("" ::"v"(acc[db][0]), "v"(acc[db][1]));
+                // features [32 s, 32 s + 32) of the step are dead after block 2 s + 1 -> refill both point tiles
+                if (has_next && (db & 1)) { dma_block(Xn, db - 1); dma_block(Xn, db); }
+                ga0 = gn0; ga1 = gn1;
+            }
+        }
+    }
+    wait_vmcnt<0>();
+
+    // ---- per-workgroup results: each wave holds the sums of ITS tile; add the four in a fixed order ----
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(sm + L::XCH_B);          // [4][2] sums, then [4][16] row sums
+    const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
+    double rv = rowsum;
+    rv += __shfl_xor(rv, 16, 64);
+    rv += __shfl_xor(rv, 32, 64);
+    if (lane == 0) { red[wave * 2 + 0] = w0; red[wave * 2 + 1] = w1; }
+    if (GRAD && g == 0) red[8 + wave * 16 + i16] = rv;
+    __syncthreads();
+    if (tid == 0) {
+        a.wg_sums[2 * (long long)bid + 0] = (red[0] + red[2]) + (red[4] + red[6]);
+        a.wg_sums[2 * (long long)bid + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+    if (GRAD) {
+        if (tid < 32) {      // row 16 t + i16: waves t and t + 2 finished its two point tiles
+            const int t = tid >> 4;
+            a.wg_rowsum[(long long)sp * a.n_rows_pad + i0 + tid] = red[8 + t * 16 + (tid & 15)] + red[8 + (t + 2) * 16 + (tid & 15)];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* grow = a.wg_grad + ((long long)sp * a.n_rows_pad + i0 + 16 * t + i16) * DPAD + wave * SW + 4 * g;
+#pragma unroll
+            for (int db = 0; db < NI; ++db) *reinterpret_cast<f32x4*>(grow + 16 * db) = acc[GRAD ? db : 0][t];
+        }
+    }
+}
+
+// ---- prep: zero-padded copies (row stride DPAD; fp32, or bf16 for the bf16 kernels), squared norms,
+//      per-wave column sums ----
+template <typename T, typename TC>
 __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, const T* __restrict__ y, int n_total,
-                                                       int n_pad, int D, int DPAD, float* __restrict__ zp,
-                                                       float* __restrict__ yp, float* __restrict__ zn,
+                                                       int n_pad, int D, int DPAD, TC* __restrict__ zp,
+                                                       TC* __restrict__ yp, float* __restrict__ zn,
                                                        float* __restrict__ yn, float* __restrict__ colpart,
                                                        int rows_per_wave, int nwaves) {
     const int lane = threadIdx.x & 63;
@@ -417,7 +712,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
     if (wg >= nwaves) return;
     const int set = blockIdx.y;
     const T* __restrict__ src = set ? y : z;
-    float* __restrict__ dst = set ? yp : zp;
+    TC* __restrict__ dst = set ? yp : zp;
     float* __restrict__ nrm = set ? yn : zn;
     const int NJ = (DPAD + 63) / 64;      // 64-column groups per row (<= 16)
     float csum[16];
@@ -432,7 +727,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
             const int c = lane + 64 * j;
             if (j < NJ && c < DPAD) {
                 const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
-                dst[(long long)row * DPAD + c] = v;
+                dst[(long long)row * DPAD + c] = from_f32<TC>(v);    // TC == bf16 only with T == bf16: exact
                 csum[j] += v;
                 sq = fmaf(v, v, sq);
             }
@@ -471,13 +766,13 @@ __global__ __launch_bounds__(1024) void mmd_shift_kernel(const float* __restrict
 
 struct FinalArgs {
     const double* wg_sums; int nwg0;     // problem-0 workgroups come first, then as many problem-1 ones
-    const double* wg_rowsum; const float* wg_grad; const float* shift; const float* zp;
+    const double* wg_rowsum; const float* wg_grad; const float* shift; const void* zp;
     int col_splits, n_rows, n_rows_pad, row_offset, D, DPAD;
     double* sums3; float* loss; double loss_scale; double grad_scale;
     void* d_z;
 };
 
-template <typename T>
+template <typename T, typename TC>
 __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
     __shared__ double red[3][256];
     const int tid = threadIdx.x;
@@ -514,7 +809,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
             rsum += f.wg_rowsum[(long long)s * f.n_rows_pad + row];
             gsum += f.wg_grad[((long long)s * f.n_rows_pad + row) * f.DPAD + c];
         }
-        const double zv = (double)f.zp[((long long)f.row_offset + row) * f.DPAD + c];
+        const double zv = (double)to_f32(static_cast<const TC*>(f.zp)[((long long)f.row_offset + row) * f.DPAD + c]);
         const double v = f.grad_scale * (-zv * rsum + (double)f.shift[c] + (double)gsum);
         out[idx] = from_f32<T>((float)v);
     }
@@ -522,6 +817,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
 
 // ---- host side ------------------------------------------------------------------------
 struct Plan {
+    int bf16_tiles;   // 1: bf16 copies + mmd_bf16_kernel<KB = DPAD / 128> (bf16 inputs, D > 192)
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
     int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_sums, off_rowsum, off_grad, bytes;
 };
@@ -539,19 +835,29 @@ const Shape* pick_shape(int64_t D) {
     return nullptr;
 }
 
-bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan* p) {
+// bf16 inputs with a wide latent run on the bf16 matrix cores (narrow ones stay on the single-wave
+// fp32 kernels, whose inputs are widened exactly)
+bool use_bf16_tiles(int dtype, int64_t D) { return dtype == TVAE_BF16 && D > 192 && D <= 1024; }
+
+bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool bf16_tiles, Plan* p) {
     const Shape* sh = pick_shape(D);
     if (!sh) return false;
+    p->bf16_tiles = bf16_tiles ? 1 : 0;
     p->NB = sh->nb;
     p->WAVES = sh->waves;
     p->DPAD = sh->dpad;
+    if (bf16_tiles) {
+        p->DPAD = (int)align_up(D, 128);
+        p->NB = p->DPAD / 128;        // KB
+        p->WAVES = 4;
+    }
     p->n_pad = (int)align_up(n_total, 2 * TILE_P);   // whole 32-point blocks (symmetric y-y enumeration)
     p->row_blocks = (int)((n_rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
     p->n_rows_pad = p->row_blocks * ROWS_PER_WG;
     p->tiles_per_set = p->n_pad / TILE_P;
     // Column splits: enough workgroups to fill the chip, and a count that fills the LAST round of
     // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
-    const int wg_per_cu = p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1);
+    const int wg_per_cu = bf16_tiles ? (p->NB <= 6 ? 2 : 1) : (p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1));
     const int slots = 256 * wg_per_cu;
     // at least 32 of the 2 * tiles_per_set column tiles per split (4 when the whole problem is tiny)
     const int max_cs = p->tiles_per_set >= 32 ? (p->tiles_per_set / 16 < 64 ? p->tiles_per_set / 16 : 64)
@@ -573,8 +879,9 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, Plan*
     p->nwaves = (p->n_pad + rpw - 1) / rpw;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
-    p->off_zp = take((int64_t)p->n_pad * p->DPAD * 4);
-    p->off_yp = take((int64_t)p->n_pad * p->DPAD * 4);
+    const int copy_elt = bf16_tiles ? 2 : 4;
+    p->off_zp = take((int64_t)p->n_pad * p->DPAD * copy_elt);
+    p->off_yp = take((int64_t)p->n_pad * p->DPAD * copy_elt);
     p->off_zn = take((int64_t)p->n_pad * 4);
     p->off_yn = take((int64_t)p->n_pad * 4);
     p->off_colpart = take((int64_t)2 * p->nwaves * p->DPAD * 4);
@@ -623,6 +930,40 @@ int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
     return fail(TVAE_ERR_ARG, "mmd: no kernel for padded dimension %d", dpad);
 }
 
+template <int KB, bool GRAD>
+int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
+    constexpr int lds_bytes = Bf16Lds<KB, GRAD>::BYTES;
+    static std::once_flag once;
+    static hipError_t attr_status = hipSuccess;
+    std::call_once(once, [] {
+        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, GRAD>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    });
+    TVAE_CHECK_HIP(attr_status);
+    hipLaunchKernelGGL((mmd_bf16_kernel<KB, GRAD>), dim3(nblocks), dim3(256), lds_bytes, s, a);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+template <bool GRAD>
+int launch_bf16_shape(int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
+    switch (kb) {
+        case 2: return launch_bf16<2, GRAD>(a, nblocks, s);
+        case 3: return launch_bf16<3, GRAD>(a, nblocks, s);
+        case 4: return launch_bf16<4, GRAD>(a, nblocks, s);
+        case 5: return launch_bf16<5, GRAD>(a, nblocks, s);
+        case 6: return launch_bf16<6, GRAD>(a, nblocks, s);
+        case 7: return launch_bf16<7, GRAD>(a, nblocks, s);
+        case 8: return launch_bf16<8, GRAD>(a, nblocks, s);
+    }
+    return fail(TVAE_ERR_ARG, "mmd: no bf16 kernel for %d feature blocks", kb);
+}
+
+template <bool GRAD>
+int launch_tiles(const Plan& p, const MmdArgs& a, int nblocks, hipStream_t s) {
+    return p.bf16_tiles ? launch_bf16_shape<GRAD>(p.NB, a, nblocks, s) : launch_tile_shape<GRAD>(p.DPAD, a, nblocks, s);
+}
+
 }  // namespace
 }  // namespace tvae
 
@@ -641,8 +982,11 @@ extern "C" int tvae_profile_next_mmd(void* ev_start, void* ev_stop) {
 }
 
 extern "C" int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad) {
-    Plan p;
-    if (n_total <= 0 || n_rows <= 0 || D <= 0 || !make_plan(n_total, n_rows, D, want_grad != 0, &p)) return -1;
+    // the dtype is not an argument here: report the larger of the two plans a call may pick
+    Plan p, q;
+    if (n_total <= 0 || n_rows <= 0 || D <= 0 || !make_plan(n_total, n_rows, D, want_grad != 0, false, &p)) return -1;
+    if (use_bf16_tiles(TVAE_BF16, D) && make_plan(n_total, n_rows, D, want_grad != 0, true, &q) && q.bytes > p.bytes)
+        return q.bytes;
     return p.bytes;
 }
 
@@ -659,15 +1003,15 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
                  (long long)row_offset, (long long)(row_offset + n_rows), (long long)n_total);
     TVAE_REQUIRE(n_total < (1ll << 30), "mmd: n_total too large");
     Plan p;
-    TVAE_REQUIRE(make_plan(n_total, n_rows, D, d_z != nullptr, &p),
+    TVAE_REQUIRE(make_plan(n_total, n_rows, D, d_z != nullptr, use_bf16_tiles(dtype, D), &p),
                  "mmd: latent dimension %lld not supported (max 1024)", (long long)D);
     if (workspace_bytes < p.bytes)
         return fail(TVAE_ERR_WORKSPACE, "mmd: workspace %lld B < required %lld B", (long long)workspace_bytes,
                     (long long)p.bytes);
     TVAE_REQUIRE(aligned16(workspace), "mmd: workspace must be 16-byte aligned");
     char* ws = static_cast<char*>(workspace);
-    float* zp = reinterpret_cast<float*>(ws + p.off_zp);
-    float* yp = reinterpret_cast<float*>(ws + p.off_yp);
+    void* zp = ws + p.off_zp;
+    void* yp = ws + p.off_yp;
     float* zn = reinterpret_cast<float*>(ws + p.off_zn);
     float* yn = reinterpret_cast<float*>(ws + p.off_yn);
     float* colpart = reinterpret_cast<float*>(ws + p.off_colpart);
@@ -675,11 +1019,17 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
 
     dim3 pgrid((p.nwaves + 3) / 4, 2);
     if (dtype == TVAE_F32)
-        hipLaunchKernelGGL(mmd_prep_kernel<float>, pgrid, dim3(256), 0, s, (const float*)z_all, (const float*)y_all,
-                           (int)n_total, p.n_pad, (int)D, p.DPAD, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
+        hipLaunchKernelGGL((mmd_prep_kernel<float, float>), pgrid, dim3(256), 0, s, (const float*)z_all,
+                           (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
+                           colpart, p.rows_per_wave, p.nwaves);
+    else if (!p.bf16_tiles)
+        hipLaunchKernelGGL((mmd_prep_kernel<bf16, float>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
+                           (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
+                           colpart, p.rows_per_wave, p.nwaves);
     else
-        hipLaunchKernelGGL(mmd_prep_kernel<bf16>, pgrid, dim3(256), 0, s, (const bf16*)z_all, (const bf16*)y_all,
-                           (int)n_total, p.n_pad, (int)D, p.DPAD, zp, yp, zn, yn, colpart, p.rows_per_wave, p.nwaves);
+        hipLaunchKernelGGL((mmd_prep_kernel<bf16, bf16>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
+                           (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (bf16*)zp, (bf16*)yp, zn, yn,
+                           colpart, p.rows_per_wave, p.nwaves);
     TVAE_CHECK_HIP(hipGetLastError());
     if (d_z) {
         hipLaunchKernelGGL(mmd_shift_kernel, dim3((p.DPAD + 63) / 64), dim3(1024), 0, s, colpart, p.nwaves, p.DPAD, shift);
@@ -687,7 +1037,7 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     }
 
     MmdArgs a;
-    a.cols[0] = zp; a.cols[1] = yp; a.cnorm[0] = zn; a.cnorm[1] = yn;
+    a.cols[0] = (const float*)zp; a.cols[1] = (const float*)yp; a.cnorm[0] = zn; a.cnorm[1] = yn;
     a.n_rows = (int)n_rows; a.n_cols = (int)n_total; a.row_offset = (int)row_offset;
     a.row_blocks = p.row_blocks; a.col_splits = p.col_splits; a.tiles_per_set = p.tiles_per_set;
     a.n_rows_pad = p.n_rows_pad;
@@ -702,12 +1052,12 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
     if (d_z) {
         a.problem_base = 0;
-        TVAE_PROPAGATE(launch_tile_shape<true>(p.DPAD, a, nwg0, s));              // z rows: sums + gradient
+        TVAE_PROPAGATE(launch_tiles<true>(p, a, nwg0, s));              // z rows: sums + gradient
         a.problem_base = 1;
-        TVAE_PROPAGATE(launch_tile_shape<false>(p.DPAD, a, nwg0, s));    // y rows: sum only
+        TVAE_PROPAGATE(launch_tiles<false>(p, a, nwg0, s));    // y rows: sum only
     } else {
         a.problem_base = 0;
-        TVAE_PROPAGATE(launch_tile_shape<false>(p.DPAD, a, 2 * nwg0, s));
+        TVAE_PROPAGATE(launch_tiles<false>(p, a, 2 * nwg0, s));
     }
     if (ev1) TVAE_CHECK_HIP(hipEventRecord(ev1, s));
 
@@ -719,8 +1069,9 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
     if (fb > 4096) fb = 4096;
     if (fb < 1) fb = 1;
-    if (dtype == TVAE_F32) hipLaunchKernelGGL(mmd_finalize_kernel<float>, dim3((unsigned)fb), dim3(256), 0, s, f);
-    else hipLaunchKernelGGL(mmd_finalize_kernel<bf16>, dim3((unsigned)fb), dim3(256), 0, s, f);
+    if (dtype == TVAE_F32) hipLaunchKernelGGL((mmd_finalize_kernel<float, float>), dim3((unsigned)fb), dim3(256), 0, s, f);
+    else if (!p.bf16_tiles) hipLaunchKernelGGL((mmd_finalize_kernel<bf16, float>), dim3((unsigned)fb), dim3(256), 0, s, f);
+    else hipLaunchKernelGGL((mmd_finalize_kernel<bf16, bf16>), dim3((unsigned)fb), dim3(256), 0, s, f);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }
