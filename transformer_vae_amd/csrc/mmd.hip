@@ -40,6 +40,7 @@ struct MmdArgs {
     int n_rows, n_cols, row_offset;
     int row_blocks, col_splits, tiles_per_set, n_rows_pad;
     int problem_base;        // first problem of this launch (0: rows = z, 1: rows = y)
+    int sums_base;           // bf16 kernels: index of this launch's first workgroup in wg_sums
     int sym;                 // 1: the y-y problem visits each unordered pair of 32-row blocks once (weight 2)
     float inv_d2;
     double* wg_sums;         // [2 * row_blocks * col_splits][2]
@@ -87,6 +88,18 @@ __device__ __forceinline__ void dma4(const float* sbase, unsigned voff, unsigned
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+// Two LDS-DMA instructions under one M0 set-up: the second lands 1 KiB further in LDS through the
+// instruction offset, which the hardware adds to the GLOBAL address as well -- voff_b is the caller's
+// per-lane offset with that 1 KiB already taken off.
+__device__ __forceinline__ void dma16_pair(const float* sbase, unsigned voff_a, unsigned voff_b, unsigned lds_byte) {
+    sbase = uniform_ptr(sbase);
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "global_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_a), "v"(voff_b), "s"(sbase), "s"(lds_byte) : "memory");
 }
 
 template <int N>
@@ -433,25 +446,43 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 constexpr int STEP_P = 32;
 
-template <int KB, bool GRAD>
+// Debug aid (make CXXFLAGS+=-DTVAE_PHASE_TIMING): workgroup 0 prints the cycles its wave 0 spent per phase.
+#ifdef TVAE_PHASE_TIMING
+#define PHASE_MARK(i) do { const unsigned long long _t = __builtin_readcyclecounter(); ph[i] += _t - ph_last; ph_last = _t; } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+
+// RT = 16-row tiles per workgroup; with 2 RT tiles per step each of the 4 waves finishes TPW = RT / 2 of
+// them.  Production uses RT = 2 (32 rows, two workgroups per CU).  RT = 4 (64 rows: half the L2 -> LDS
+// traffic per flop, but 434 registers per lane = one wave per SIMD) was measured SLOWER at every width
+// (N = 32768: D = 768 11.3 ms vs 9.05 ms, D = 256 5.06 vs 4.49): with 16-cycle MFMAs the second resident
+// workgroup, which hides the exchange / expm1 / barrier phases, is worth more than the halved traffic.
+template <int KB, int RT, bool GRAD>
 struct Bf16Lds {
     static constexpr int SW = 32 * KB;                       // bf16 features per wave
+    static constexpr int TPW = RT / 2;                       // S' tiles finished per wave
     static constexpr int SLICE_B = STEP_P * SW * 2;          // bytes of one wave's slice of a 32-point step
     static constexpr int NORM_B = 4 * SLICE_B;               // [2 buf][4 waves][32] float point norms
     static constexpr int XCH_B = NORM_B + 2 * 4 * STEP_P * 4;
-    static constexpr int XCH_ONE_B = 12 * 64 * 16;           // [dst tile][3 remote sources][64 lanes] float4
+    static constexpr int XCH_ONE_B = 2 * RT * 3 * 64 * 16;   // [tile][3 remote sources][64 lanes] float4
     // the gradient instantiation has a second barrier per step, which also protects a single exchange buffer
     static constexpr int XBUFS = GRAD ? 1 : (KB <= 6 ? 2 : 1);
-    static constexpr int EBUF_B = XCH_B + XBUFS * XCH_ONE_B; // [2 row tiles][64 lanes][2 point tiles] 4 x bf16
-    static constexpr int BYTES = EBUF_B + (GRAD ? 2 * 64 * 16 : 0);
+    static constexpr int EBUF_B = XCH_B + XBUFS * XCH_ONE_B; // [RT row tiles][64 lanes][2 point tiles] 4 x bf16
+    static constexpr int BYTES = EBUF_B + (GRAD ? RT * 64 * 16 : 0);
+    // two workgroups per CU when LDS and registers (<= 256 per lane) both allow it
+    static constexpr int WG_PER_CU = (RT == 2 && KB <= 6) ? 2 : 1;
+    static_assert(RT == 2 || RT == 4, "2 or 4 row tiles");
     static_assert(BYTES <= 160 * 1024, "bf16 tile kernel exceeds the 160 KiB LDS");
-    static_assert(XCH_ONE_B >= 4 * 18 * 8, "final reduction reuses the exchange buffer");
+    static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses the exchange buffer");
 };
 
-template <int KB, bool GRAD>
-__global__ __launch_bounds__(256, (KB <= 6 ? 2 : 1)) void mmd_bf16_kernel(MmdArgs a) {
-    using L = Bf16Lds<KB, GRAD>;
+template <int KB, int RT, bool GRAD>
+__global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
+    using L = Bf16Lds<KB, RT, GRAD>;
+    static_assert(GRAD || RT == 2, "the symmetric y-y enumeration assumes 32-row blocks");
     constexpr int SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;     // NI: DMA instructions = 16-feature blocks per slice
+    constexpr int TPW = L::TPW, ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -460,21 +491,22 @@ __global__ __launch_bounds__(256, (KB <= 6 ? 2 : 1)) void mmd_bf16_kernel(MmdArg
     const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned xs_byte = smem_byte + (unsigned)(wave * L::SLICE_B);
     const char* xs = sm + wave * L::SLICE_B;
-    const int my_pt = wave >> 1, my_t = wave & 1;             // the S' tile this wave finishes
+    // the S' tiles this wave finishes: point tile my_pt, row tiles my_t0 .. my_t0 + TPW - 1
+    const int my_pt = wave >> 1, my_t0 = (wave & 1) * TPW;
 
     const int per_problem = a.row_blocks * a.col_splits;
-    const int bid = a.problem_base * per_problem + blockIdx.x;
-    const int problem = GRAD ? 0 : bid / per_problem;
-    const int rem = bid - problem * per_problem;
+    const int problem = GRAD ? 0 : a.problem_base + (int)blockIdx.x / per_problem;
+    const int rem = (int)blockIdx.x - (problem - a.problem_base) * per_problem;
     const int rb = rem / a.col_splits, sp = rem - rb * a.col_splits;
-    const int i0 = rb * ROWS_PER_WG;
+    const int i0 = rb * ROWS;
+    const long long bid = (long long)a.sums_base + blockIdx.x;
 
-    // ---- the 32 rows of this workgroup: this wave's feature slice, in registers as MFMA B operands ----
+    // ---- the rows of this workgroup: this wave's feature slice, in registers as MFMA B operands ----
     const bf16* rows = reinterpret_cast<const bf16*>(a.cols[problem]) + (long long)a.row_offset * DPAD;
     const float* rnorm = a.cnorm[problem] + a.row_offset;
-    bf16x8_t zreg[2][KB];
+    bf16x8_t zreg[RT][KB];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < RT; ++t) {
         const int row = i0 + 16 * t + i16;
         const bf16* zp = rows + (long long)row * DPAD + wave * SW + 8 * g;
 #pragma unroll
@@ -483,22 +515,30 @@ __global__ __launch_bounds__(256, (KB <= 6 ? 2 : 1)) void mmd_bf16_kernel(MmdArg
             else zreg[t][s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    const int my_row = i0 + 16 * my_t + i16;
-    const bool my_valid = my_row < a.n_rows;
-    float rn = my_valid ? rnorm[my_row] : 0.f;
+    bool my_valid[TPW];
+    float rn[TPW];
+    bool all_valid = true;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int j = 0; j < TPW; ++j) {
+        const int my_row = i0 + 16 * (my_t0 + j) + i16;
+        my_valid[j] = my_row < a.n_rows;
+        rn[j] = my_valid[j] ? rnorm[my_row] : 0.f;
+        all_valid = all_valid && my_valid[j];
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int s = 0; s < KB; ++s) asm volatile("" : "+v"(zreg[t][s]));
-    asm volatile("" : "+v"(rn));
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) asm volatile("" : "+v"(rn[j]));
+    const bool any_invalid = __any(!all_valid);
 
-    f32x4 acc[GRAD ? NI : 1][2];
+    f32x4 acc[GRAD ? NI : 1][RT];
     if (GRAD) {
 #pragma unroll
-        for (int db = 0; db < NI; ++db) {
-            acc[db][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[db][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int db = 0; db < NI; ++db)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[db][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // 32-point steps; the symmetric y-y enumeration is the fp32 kernel's (one step = one block J)
@@ -545,153 +585,245 @@ __global__ __launch_bounds__(256, (KB <= 6 ? 2 : 1)) void mmd_bf16_kernel(MmdArg
         const float* src = uniform_ptr(a.cnorm[set] + p0);
         if (lane < STEP_P) dma4(src, (unsigned)lane * 4u, dst);
     };
-    auto dma_block = [&](const bf16* X, int i) {      // i = 2 s + a
-        dma16(reinterpret_cast<const float*>(X + (long long)(16 * (i & 1)) * DPAD + 32 * (i >> 1)), dma_voff,
-              xs_byte + 1024u * i);
+    const unsigned dma_voff_b = dma_voff + 16u * DPAD * 2u - 1024u;      // second point tile, see dma16_pair
+    auto dma_pair = [&](const bf16* X, int s) {       // features [32 s, 32 s + 32) of both point tiles
+        dma16_pair(reinterpret_cast<const float*>(X + 32 * s), dma_voff, dma_voff_b, xs_byte + 2048u * s);
     };
 
-    double sum0 = 0.0, sum1 = 0.0, rowsum = 0.0;
+    double sum0 = 0.0, sum1 = 0.0, rowsum[TPW];
+    float f0 = 0.f, f1 = 0.f, fr[TPW];      // fp32 partials of the sums, flushed to fp64 every 8 steps
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) { rowsum[j] = 0.0; fr[j] = 0.f; }
 
-    // DMA issue order: norms(k) ... X(k) blocks 0..NI-1 ...; norms(k+1) at the top of iteration k
+    // DMA issue order: norms(k) ... X(k) blocks 0..NI-1 ...; norms(k+1) at the top of iteration k.
+    // The last step prefetches ITSELF again (harmless, once per workgroup): no branch around any DMA, and
+    // the counted waits hold on every iteration.
     if (sb < se) {
         stage_norms(sb, 0);
         const bf16* X0 = step_src(sb);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) dma_block(X0, i);
+        for (int s = 0; s < KB; ++s) dma_pair(X0, s);
     }
+#ifdef TVAE_PHASE_TIMING
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
+#endif
     for (int step = sb; step < se; ++step) {
+        PHASE_MARK(5);
         const int u = actual(step);
         const int set = u >= nJ ? 1 : 0;
         const int p0 = (u - set * nJ) * STEP_P;
         const float wsym = (sym && (p0 >> 5) != blkI) ? 2.f : 1.f;
         const int buf = (step - sb) & 1;
-        const bool has_next = step + 1 < se;
-        const bf16* Xn = step_src(has_next ? step + 1 : step);
-        if (has_next) stage_norms(step + 1, buf ^ 1);
-        else wait_vmcnt<0>();
+        const int nstep = step + 1 < se ? step + 1 : step;
+        const bf16* Xn = step_src(nstep);
+        stage_norms(nstep, buf ^ 1);
 
         // 1. partial Gram over the slice: S[pt][t] (16 points x 16 rows each)
-        f32x4 S00 = {0.f, 0.f, 0.f, 0.f}, S01 = S00, S10 = S00, S11 = S00;
-        wait_vmcnt<NI - 1>();
-        bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xs + gram_off);
-        bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 1024);
+        //    The operand reads run GD k-steps ahead of their MFMAs.  Before the read of k-step s the DMAs
+        //    still allowed in flight are the younger blocks of this step, norms(k+1) and -- sum-only
+        //    instantiation, which refills block pair s right after its MFMAs -- the pairs of the next step
+        //    already issued.
+        f32x4 S[2][RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) S[0][t] = S[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int GD = KB < 2 ? KB : 2;
+        bf16x8_t ab[KB][2];
+        auto gram_wait = [&](int sr, int issued_pairs) { wait_vmcnt_n(NI - 2 * sr - 1 + (GRAD ? 0 : 2 * issued_pairs)); };
+#pragma unroll
+        for (int s = 0; s < GD; ++s) {
+            gram_wait(s, 0);
+            ab[s][0] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * s);
+            ab[s][1] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * s + 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KB; ++s) {
-            bf16x8_t n0 = a0, n1 = a1;
-            if (s + 1 < KB) {
-                wait_vmcnt_n(GRAD ? NI - 2 * (s + 1) - 1 : NI - 3);
-                n0 = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + 1));
-                n1 = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + 1) + 1024);
+            if (s + GD < KB) {
+                gram_wait(s + GD, s);
+                ab[s + GD][0] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + GD));
+                ab[s + GD][1] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + GD) + 1024);
             }
-            S00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, zreg[0][s], S00, 0, 0, 0);
-            S01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, zreg[1][s], S01, 0, 0, 0);
-            S10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, zreg[0][s], S10, 0, 0, 0);
-            S11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, zreg[1][s], S11, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads GD k-steps ahead (hipcc sinks them otherwise)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                S[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][0], zreg[t][s], S[0][t], 0, 0, 0);
+                S[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][1], zreg[t][s], S[1][t], 0, 0, 0);
+            }
             if (!GRAD) {
-                asm volatile("" ::"v"(S00), "v"(S01), "v"(S10), "v"(S11));
-                if (has_next) { dma_block(Xn, 2 * s); dma_block(Xn, 2 * s + 1); }
+#pragma unroll
+                for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(S[0][t]), "v"(S[1][t]));
+                dma_pair(Xn, s);
             }
-            a0 = n0; a1 = n1;
         }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(S[0][t]), "v"(S[1][t]));
+        PHASE_MARK(0);
 
-        // 2. reduce-scatter of the partials: tile q4 = 2 pt + t goes to wave q4
+        // 2. reduce-scatter of the partials: tile q = RT pt + t goes to wave q / TPW
         f32x4* xb = reinterpret_cast<f32x4*>(sm + L::XCH_B + (L::XBUFS == 2 ? buf * L::XCH_ONE_B : 0));
-        if (wave != 0) xb[(0 * 3 + ((wave - 0 - 1) & 3)) * 64 + lane] = S00;
-        if (wave != 1) xb[(1 * 3 + ((wave - 1 - 1) & 3)) * 64 + lane] = S01;
-        if (wave != 2) xb[(2 * 3 + ((wave - 2 - 1) & 3)) * 64 + lane] = S10;
-        if (wave != 3) xb[(3 * 3 + ((wave - 3 - 1) & 3)) * 64 + lane] = S11;
+#pragma unroll
+        for (int q = 0; q < 2 * RT; ++q) {
+            const int owner = q / TPW;
+            if (wave != owner) xb[(q * 3 + ((wave - owner - 1) & 3)) * 64 + lane] = S[q / RT][q % RT];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        f32x4 sv = wave == 0 ? S00 : (wave == 1 ? S01 : (wave == 2 ? S10 : S11));
-        sv += xb[(wave * 3 + 0) * 64 + lane];
-        sv += xb[(wave * 3 + 1) * 64 + lane];
-        sv += xb[(wave * 3 + 2) * 64 + lane];
+        PHASE_MARK(1);
+        f32x4 sv[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            // own partial: tile (pt = wave >> 1, t = (wave & 1) TPW + j)
+            sv[j] = wave == 0 ? S[0][j] : (wave == 1 ? S[0][TPW + j] : (wave == 2 ? S[1][j] : S[1][TPW + j]));
+            const int q = wave * TPW + j;
+            sv[j] += xb[(q * 3 + 0) * 64 + lane];
+            sv[j] += xb[(q * 3 + 1) * 64 + lane];
+            sv[j] += xb[(q * 3 + 2) * 64 + lane];
+        }
         if (!GRAD && L::XBUFS == 1) {       // single exchange buffer without the E barrier: fence the reads
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
 
-        // 3. E = expm1(-t) for this wave's tile; register r <-> point p0 + 16 pt + 4 g + r, column = row i16
+        // 3. E = expm1(-t) for this wave's tiles; register r <-> point p0 + 16 pt + 4 g + r, column = row i16
         const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_B + ((buf * 4 + wave) * STEP_P + 16 * my_pt + 4 * g) * 4);
-        f32x4 tt, e;
+        f32x4 e[TPW];
+        float tmax = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            tt[r] = fmaxf((cn[r] + rn - 2.f * sv[r]) * a.inv_d2, 0.f);
-            e[r] = em1_neg(tt[r]);
-        }
-        if (__any(fmaxf(fmaxf(tt[0], tt[1]), fmaxf(tt[2], tt[3])) >= 0.125f)) {
+        for (int j = 0; j < TPW; ++j) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (tt[r] >= 0.125f) e[r] = expm1f(-tt[r]);
+            for (int r = 0; r < 4; ++r) {
+                const float tt = fmaxf((cn[r] + rn[j] - 2.f * sv[j][r]) * a.inv_d2, 0.f);
+                sv[j][r] = tt;
+                e[j][r] = em1_neg(tt);
+                tmax = fmaxf(tmax, tt);
+            }
         }
-        if (!my_valid) e = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (__any(tmax >= 0.125f)) {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (sv[j][r] >= 0.125f) e[j][r] = expm1f(-sv[j][r]);
+        }
+        if (any_invalid) {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+                if (!my_valid[j]) e[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (p0 + STEP_P > a.n_cols) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (p0 + 16 * my_pt + 4 * g + r >= a.n_cols) e[r] = 0.f;
+                if (p0 + 16 * my_pt + 4 * g + r >= a.n_cols) {
+#pragma unroll
+                    for (int j = 0; j < TPW; ++j) e[j][r] = 0.f;
+                }
         }
-        const float es = (e[0] + e[1]) + (e[2] + e[3]);
-        if (set) { sum1 += (double)(wsym * es); rowsum -= (double)es; }
-        else { sum0 += (double)es; rowsum += (double)es; }
+        float es_all = 0.f;
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const float es = (e[j][0] + e[j][1]) + (e[j][2] + e[j][3]);
+            es_all += es;
+            fr[j] += set ? -es : es;
+        }
+        if (set) f1 = fmaf(wsym, es_all, f1);
+        else f0 += es_all;
+        if (((step - sb) & 7) == 7) {
+            sum0 += (double)f0; sum1 += (double)f1;
+            f0 = f1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) { rowsum[j] += (double)fr[j]; fr[j] = 0.f; }
+        }
 
         // 4. gradient: acc^T[d][i] += X^T[d][p] (s_p E[p][i]) over the 32 points of the step in ONE k-step
         if (GRAD) {
-            if (set) e = -e;
-            bf16x4_t eb;
+            uint2* ebuf = reinterpret_cast<uint2*>(sm + L::EBUF_B);
+            // prior columns enter the gradient with s_p = -1: flip the four sign bits of the packed values
+            const unsigned flip = set ? 0x80008000u : 0u;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) eb[r] = (__bf16)e[r];
-            bf16x4_t* ebuf = reinterpret_cast<bf16x4_t*>(sm + L::EBUF_B);
-            ebuf[(my_t * 64 + lane) * 2 + my_pt] = eb;
+            for (int j = 0; j < TPW; ++j) {
+                bf16x4_t eb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) eb[r] = (__bf16)e[j][r];
+                uint2 ebits = __builtin_bit_cast(uint2, eb);
+                ebits.x ^= flip; ebits.y ^= flip;
+                ebuf[((my_t0 + j) * 64 + lane) * 2 + my_pt] = ebits;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PHASE_MARK(2);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const bf16x8_t E0 = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (0 * 64 + lane) * 16);
-            const bf16x8_t E1 = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (1 * 64 + lane) * 16);
+            PHASE_MARK(3);
+            bf16x8_t Eb[RT];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) Eb[t] = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (t * 64 + lane) * 16);
             const int tb0 = wave * L::SLICE_B + tr_off0, tb1 = wave * L::SLICE_B + tr_off1;
-            s16x4_t ga0 = tr_read(tb0), ga1 = tr_read(tb0 + 1024);
+            // transposed operand reads run TD blocks ahead of their MFMAs
+            constexpr int TD = NI < 3 ? NI : 3;
+            s16x4_t ga[NI][2];
+            auto grad_read = [&](int db) {
+                const int nb = ((db & 1) ? tb1 : tb0) + 2048 * (db >> 1);
+                ga[db][0] = tr_read(nb);
+                ga[db][1] = tr_read(nb + 1024);
+            };
+#pragma unroll
+            for (int db = 0; db < TD; ++db) grad_read(db);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int db = 0; db < NI; ++db) {
-                s16x4_t gn0 = ga0, gn1 = ga1;
-                if (db + 1 < NI) {
-                    const int nb = (((db + 1) & 1) ? tb1 : tb0) + 2048 * ((db + 1) >> 1);
-                    gn0 = tr_read(nb);
-                    gn1 = tr_read(nb + 1024);
-                }
-                const s16x8_t av = __builtin_shufflevector(ga0, ga1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8_t ab = __builtin_bit_cast(bf16x8_t, av);
-                acc[db][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, E0, acc[db][0], 0, 0, 0);
-                acc[db][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, E1, acc[db][1], 0, 0, 0);
-                asm volatile("" ::"v"(acc[db][0]), "v"(acc[db][1]));
+                if (db + TD < NI) grad_read(db + TD);
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads TD blocks ahead
+                const s16x8_t av = __builtin_shufflevector(ga[db][0], ga[db][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t ab2 = __builtin_bit_cast(bf16x8_t, av);
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+                    acc[db][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab2, Eb[t], acc[db][t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(acc[db][t]));
                 // features [32 s, 32 s + 32) of the step are dead after block 2 s + 1 -> refill both point tiles
-                if (has_next && (db & 1)) { dma_block(Xn, db - 1); dma_block(Xn, db); }
-                ga0 = gn0; ga1 = gn1;
+                if (db & 1) dma_pair(Xn, db >> 1);
             }
+            PHASE_MARK(4);
         }
     }
+#ifdef TVAE_PHASE_TIMING
+    if (blockIdx.x == 0 && lane == 0)
+        printf("wave %d steps %d: gram %llu  xch+barrier %llu  E %llu  barrier2 %llu  grad %llu  top %llu (cycles per step)\n", wave,
+               se - sb, ph[0] / (se - sb), ph[1] / (se - sb), ph[2] / (se - sb), ph[3] / (se - sb), ph[4] / (se - sb),
+               ph[5] / (se - sb));
+#endif
     wait_vmcnt<0>();
+    sum0 += (double)f0; sum1 += (double)f1;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) rowsum[j] += (double)fr[j];
 
-    // ---- per-workgroup results: each wave holds the sums of ITS tile; add the four in a fixed order ----
+    // ---- per-workgroup results: each wave holds the sums of ITS tiles; add the four in a fixed order ----
     __syncthreads();
-    double* red = reinterpret_cast<double*>(sm + L::XCH_B);          // [4][2] sums, then [4][16] row sums
+    double* red = reinterpret_cast<double*>(sm + L::XCH_B);          // [4][2] sums, then [4 TPW][16] row sums
     const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
-    double rv = rowsum;
-    rv += __shfl_xor(rv, 16, 64);
-    rv += __shfl_xor(rv, 32, 64);
     if (lane == 0) { red[wave * 2 + 0] = w0; red[wave * 2 + 1] = w1; }
-    if (GRAD && g == 0) red[8 + wave * 16 + i16] = rv;
+    if (GRAD) {
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            double rv = rowsum[j];
+            rv += __shfl_xor(rv, 16, 64);
+            rv += __shfl_xor(rv, 32, 64);
+            if (g == 0) red[8 + (wave * TPW + j) * 16 + i16] = rv;
+        }
+    }
     __syncthreads();
     if (tid == 0) {
-        a.wg_sums[2 * (long long)bid + 0] = (red[0] + red[2]) + (red[4] + red[6]);
-        a.wg_sums[2 * (long long)bid + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+        a.wg_sums[2 * bid + 0] = (red[0] + red[2]) + (red[4] + red[6]);
+        a.wg_sums[2 * bid + 1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
     if (GRAD) {
-        if (tid < 32) {      // row 16 t + i16: waves t and t + 2 finished its two point tiles
-            const int t = tid >> 4;
-            a.wg_rowsum[(long long)sp * a.n_rows_pad + i0 + tid] = red[8 + t * 16 + (tid & 15)] + red[8 + (t + 2) * 16 + (tid & 15)];
+        if (tid < ROWS) {    // row 16 t + i: slot (wave * TPW + j) with t = (wave & 1) TPW + j, point tiles wave >> 1 = 0, 1
+            const int t = tid >> 4, i = tid & 15;
+            const int slot = (t / TPW) * TPW + (t % TPW);          // wave (t / TPW), j = t % TPW
+            a.wg_rowsum[(long long)sp * a.n_rows_pad + i0 + tid] = red[8 + slot * 16 + i] + red[8 + (slot + 2 * TPW) * 16 + i];
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < RT; ++t) {
             float* grow = a.wg_grad + ((long long)sp * a.n_rows_pad + i0 + 16 * t + i16) * DPAD + wave * SW + 4 * g;
 #pragma unroll
             for (int db = 0; db < NI; ++db) *reinterpret_cast<f32x4*>(grow + 16 * db) = acc[GRAD ? db : 0][t];
@@ -765,7 +897,7 @@ __global__ __launch_bounds__(1024) void mmd_shift_kernel(const float* __restrict
 }
 
 struct FinalArgs {
-    const double* wg_sums; int nwg0;     // problem-0 workgroups come first, then as many problem-1 ones
+    const double* wg_sums; int nwg0, nwg1;   // nwg0 problem-0 workgroups come first, then nwg1 problem-1 ones
     const double* wg_rowsum; const float* wg_grad; const float* shift; const void* zp;
     int col_splits, n_rows, n_rows_pad, row_offset, D, DPAD;
     double* sums3; float* loss; double loss_scale; double grad_scale;
@@ -781,8 +913,8 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
         for (int w = tid; w < f.nwg0; w += 256) {
             zz += f.wg_sums[2 * (long long)w + 0];
             zy += f.wg_sums[2 * (long long)w + 1];
-            yy += f.wg_sums[2 * ((long long)f.nwg0 + w) + 1];
         }
+        for (int w = tid; w < f.nwg1; w += 256) yy += f.wg_sums[2 * ((long long)f.nwg0 + w) + 1];
         red[0][tid] = zz; red[1][tid] = zy; red[2][tid] = yy;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
@@ -818,6 +950,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
 // ---- host side ------------------------------------------------------------------------
 struct Plan {
     int bf16_tiles;   // 1: bf16 copies + mmd_bf16_kernel<KB = DPAD / 128> (bf16 inputs, D > 192)
+    int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
     int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_sums, off_rowsum, off_grad, bytes;
 };
@@ -853,11 +986,14 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     }
     p->n_pad = (int)align_up(n_total, 2 * TILE_P);   // whole 32-point blocks (symmetric y-y enumeration)
     p->row_blocks = (int)((n_rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
-    p->n_rows_pad = p->row_blocks * ROWS_PER_WG;
+    p->RT = 2;        // see Bf16Lds: 64-row blocks (RT = 4) lose the second resident workgroup and measured slower
+    p->row_blocks_g = (int)((n_rows + 16 * p->RT - 1) / (16 * p->RT));
+    p->n_rows_pad = p->row_blocks_g * 16 * p->RT;
     p->tiles_per_set = p->n_pad / TILE_P;
     // Column splits: enough workgroups to fill the chip, and a count that fills the LAST round of
     // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
-    const int wg_per_cu = bf16_tiles ? (p->NB <= 6 ? 2 : 1) : (p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1));
+    const int wg_per_cu = bf16_tiles ? ((p->RT == 2 && p->NB <= 6) ? 2 : 1)
+                                     : (p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1));
     const int slots = 256 * wg_per_cu;
     // at least 32 of the 2 * tiles_per_set column tiles per split (4 when the whole problem is tiny)
     const int max_cs = p->tiles_per_set >= 32 ? (p->tiles_per_set / 16 < 64 ? p->tiles_per_set / 16 : 64)
@@ -865,7 +1001,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     int cs = 1;
     double best = 1e30;
     for (int c = 1; c <= max_cs; ++c) {
-        const double rounds = (double)p->row_blocks * c / slots;
+        const double rounds = (double)p->row_blocks_g * c / slots;
         const double waste = (rounds < 1.0 ? 1.0 / rounds : ((double)(long long)(rounds + 0.999999)) / rounds);
         // prefer fewer splits unless a larger count is at least 2 % better
         if (waste < best * 0.98) { best = waste; cs = c; }
@@ -886,7 +1022,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     p->off_yn = take((int64_t)p->n_pad * 4);
     p->off_colpart = take((int64_t)2 * p->nwaves * p->DPAD * 4);
     p->off_shift = take((int64_t)p->DPAD * 4);
-    p->off_sums = take((int64_t)2 * p->row_blocks * p->col_splits * 2 * 8);
+    p->off_sums = take((int64_t)(2 * p->row_blocks + p->row_blocks_g) * p->col_splits * 2 * 8);
     p->off_rowsum = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * 8 : 0);
     p->off_grad = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * p->DPAD * 4 : 0);
     p->bytes = off;
@@ -930,17 +1066,30 @@ int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
     return fail(TVAE_ERR_ARG, "mmd: no kernel for padded dimension %d", dpad);
 }
 
-template <int KB, bool GRAD>
+// With -DTVAE_PHASE_TIMING the environment variable TVAE_DEBUG_LDS_PAD (bytes) inflates the dynamic LDS of
+// the bf16 kernels to lower the number of resident workgroups for an experiment; otherwise both are zero.
+#ifdef TVAE_PHASE_TIMING
+constexpr int kDebugLdsPadMax = 64 * 1024;
+int debug_lds_pad() {
+    static const int pad = getenv("TVAE_DEBUG_LDS_PAD") ? atoi(getenv("TVAE_DEBUG_LDS_PAD")) : 0;
+    return pad < 0 ? 0 : (pad > kDebugLdsPadMax ? kDebugLdsPadMax : pad);
+}
+#else
+constexpr int kDebugLdsPadMax = 0;
+constexpr int debug_lds_pad() { return 0; }
+#endif
+
+template <int KB, int RT, bool GRAD>
 int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
-    constexpr int lds_bytes = Bf16Lds<KB, GRAD>::BYTES;
+    constexpr int lds_bytes = Bf16Lds<KB, RT, GRAD>::BYTES;
     static std::once_flag once;
     static hipError_t attr_status = hipSuccess;
     std::call_once(once, [] {
-        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, GRAD>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes + kDebugLdsPadMax);
     });
     TVAE_CHECK_HIP(attr_status);
-    hipLaunchKernelGGL((mmd_bf16_kernel<KB, GRAD>), dim3(nblocks), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD>), dim3(nblocks), dim3(256), lds_bytes + debug_lds_pad(), s, a);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }
@@ -948,13 +1097,13 @@ int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
 template <bool GRAD>
 int launch_bf16_shape(int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
     switch (kb) {
-        case 2: return launch_bf16<2, GRAD>(a, nblocks, s);
-        case 3: return launch_bf16<3, GRAD>(a, nblocks, s);
-        case 4: return launch_bf16<4, GRAD>(a, nblocks, s);
-        case 5: return launch_bf16<5, GRAD>(a, nblocks, s);
-        case 6: return launch_bf16<6, GRAD>(a, nblocks, s);
-        case 7: return launch_bf16<7, GRAD>(a, nblocks, s);
-        case 8: return launch_bf16<8, GRAD>(a, nblocks, s);
+        case 2: return launch_bf16<2, 2, GRAD>(a, nblocks, s);
+        case 3: return launch_bf16<3, 2, GRAD>(a, nblocks, s);
+        case 4: return launch_bf16<4, 2, GRAD>(a, nblocks, s);
+        case 5: return launch_bf16<5, 2, GRAD>(a, nblocks, s);
+        case 6: return launch_bf16<6, 2, GRAD>(a, nblocks, s);
+        case 7: return launch_bf16<7, 2, GRAD>(a, nblocks, s);
+        case 8: return launch_bf16<8, 2, GRAD>(a, nblocks, s);
     }
     return fail(TVAE_ERR_ARG, "mmd: no bf16 kernel for %d feature blocks", kb);
 }
@@ -1046,23 +1195,25 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     a.wg_sums = reinterpret_cast<double*>(ws + p.off_sums);
     a.wg_rowsum = reinterpret_cast<double*>(ws + p.off_rowsum);
     a.wg_grad = reinterpret_cast<float*>(ws + p.off_grad);
-    const int nwg0 = p.row_blocks * p.col_splits;
+    // workgroups of the two problems (the bf16 gradient launch has its own, larger, row blocks)
+    const int nwg_sum = p.row_blocks * p.col_splits;
+    const int nwg0 = d_z ? p.row_blocks_g * p.col_splits : nwg_sum, nwg1 = nwg_sum;
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
     if (d_z) {
-        a.problem_base = 0;
+        a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks_g;
         TVAE_PROPAGATE(launch_tiles<true>(p, a, nwg0, s));              // z rows: sums + gradient
-        a.problem_base = 1;
-        TVAE_PROPAGATE(launch_tiles<false>(p, a, nwg0, s));    // y rows: sum only
+        a.problem_base = 1; a.sums_base = nwg0; a.row_blocks = p.row_blocks;
+        TVAE_PROPAGATE(launch_tiles<false>(p, a, nwg1, s));    // y rows: sum only
     } else {
-        a.problem_base = 0;
-        TVAE_PROPAGATE(launch_tiles<false>(p, a, 2 * nwg0, s));
+        a.problem_base = 0; a.sums_base = 0;
+        TVAE_PROPAGATE(launch_tiles<false>(p, a, 2 * nwg_sum, s));
     }
     if (ev1) TVAE_CHECK_HIP(hipEventRecord(ev1, s));
 
     FinalArgs f;
-    f.wg_sums = a.wg_sums; f.nwg0 = nwg0; f.wg_rowsum = a.wg_rowsum; f.wg_grad = a.wg_grad; f.shift = shift; f.zp = zp;
+    f.wg_sums = a.wg_sums; f.nwg0 = nwg0; f.nwg1 = nwg1; f.wg_rowsum = a.wg_rowsum; f.wg_grad = a.wg_grad; f.shift = shift; f.zp = zp;
     f.col_splits = p.col_splits; f.n_rows = (int)n_rows; f.n_rows_pad = p.n_rows_pad; f.row_offset = (int)row_offset;
     f.D = (int)D; f.DPAD = p.DPAD; f.sums3 = sums3; f.loss = loss; f.loss_scale = loss_scale; f.grad_scale = grad_scale;
     f.d_z = d_z;
