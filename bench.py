@@ -130,6 +130,61 @@ def cpu_baseline(cfg_name, world):
                       f"(sums + gradient) and {bs} of {B} sequences through the projections, scaled to the full step"}
 
 
+def side_config(cfg_name, device, graphed):
+    """A bounded run of one of the small BASELINE configs on this GPU (rank 0, N=1 only): the headline stays
+    on the default workload, these ride along in `other_configs`.  `graphed`: the whole step (forward, loss,
+    backward) captured once into a HIP graph and replayed -- the launch-bound configs spend their time in
+    ~30 kernel launches and the autograd bookkeeping around them."""
+    B, S, d, n, L, cfg_id, label = CONFIGS[cfg_name]
+    n_eff = min(n, S)
+    N = B * n_eff
+    vae = make_vae(d, L, n, device, torch.float32, "local", 1)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + cfg_id)
+    h = torch.randn((B, S, d), generator=gen, device=device).requires_grad_(True)
+    gen.manual_seed(4321 + cfg_id)
+    prior = torch.randn((N, L), generator=gen, device=device)
+    gen.manual_seed(99)
+    g0 = torch.randn((B, n_eff, d), generator=gen, device=device) / (N * d) ** 0.5
+    params = list(vae.parameters())
+
+    def step():
+        out = vae(input_encoding=h, true_samples=prior)
+        loss = out.reg_loss * REG_W + (out.reconstructed_encoding * g0).sum()
+        loss.backward()
+        return out.reg_loss
+
+    def clear():
+        h.grad = None
+        for p in params:
+            p.grad = None
+
+    for _ in range(3):
+        clear()
+        step()
+    torch.cuda.synchronize(device)
+    steps = 200 if cfg_name in ("cfg1", "cfg2") else 20
+    if graphed:
+        from transformer_vae_amd.graph import GraphedStep
+        gs = GraphedStep(lambda hh, pp: step(), (h, prior), zero_grads=[h] + params)
+        run = lambda: gs(h, prior)
+    else:
+        def run():
+            clear()
+            return step()
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize(device)
+    sec = (time.perf_counter() - t0) / steps
+    assert h.grad is not None and bool(torch.isfinite(h.grad).all())
+    return {"workload": f"{cfg_name}: {label}", "value": B / sec, "unit": "samples/s", "ms_per_step": sec * 1e3,
+            "steps": steps, "hip_graph": bool(graphed)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +195,8 @@ def main():
     ap.add_argument("--mmd-dtype", default="ref", choices=["ref", "bf16"],
                     help="ref: the reference's promotion (fp32 against its fp32 prior); bf16: opt-in bf16 matrix-core MMD")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the bounded cfg1/cfg2/cfg3 runs reported under other_configs (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,6 +318,16 @@ def main():
             except Exception as e:      # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e!r}"}
+        if world == 1 and not args.no_side_configs:
+            others = []
+            for name, graphed in (("cfg1", False), ("cfg1", True), ("cfg2", False), ("cfg2", True), ("cfg3", False)):
+                if name == args.config:
+                    continue
+                try:
+                    others.append(side_config(name, device, graphed))
+                except Exception as e:
+                    others.append({"workload": name, "hip_graph": graphed, "value": None, "error": repr(e)[:200]})
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -10,9 +10,10 @@ from .autoencoders import (EncoderDecoderVAE, LatentDecoder, LatentDecoderFunnel
 from .model_outputs import BaseVAE_Output
 from .utils import slerp, upsample
 from . import losses, trainer
+from .graph import GraphedStep
 
 build = _lib.build
 
 __all__ = ["EncoderDecoderVAE", "LatentEncoderNTokens", "LatentEncoderLargeTanh", "LatentDecoderNTokens",
            "LatentDecoderFunnelNorm", "LatentDecoderT5Norm", "LatentDecoder", "VAE_ENCODER_MODELS",
-           "VAE_DECODER_MODELS", "BaseVAE_Output", "slerp", "upsample", "losses", "trainer", "build"]
+           "VAE_DECODER_MODELS", "BaseVAE_Output", "slerp", "upsample", "losses", "trainer", "GraphedStep", "build"]
