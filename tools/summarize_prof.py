@@ -15,14 +15,15 @@ for d in ["pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"]:
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         calls = collections.Counter()
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"][:90]
+            k = r["Kernel_Name"][:70]
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         ids = collections.defaultdict(set)
         for r in csv.DictReader(open(f)):
-            ids[r["Kernel_Name"][:90]].add(r["Dispatch_Id"])
+            ids[r["Kernel_Name"][:70]].add(r["Dispatch_Id"])
         out.append(f"# rocprofv3 --pmc pass {d}: counter sums over all dispatches of the kernel (dispatch count in brackets)")
         for k, v in agg.items():
             if "tvae" in k:
-                out.append(f"{k} [{len(ids[k])}] " + " ".join(f"{a}={b:.0f}" for a, b in sorted(v.items())))
+                out.append(f"{k} [{len(ids[k])}]")
+                out.append("    " + " ".join(f"{a}={b:.0f}" for a, b in sorted(v.items())))
 open(dst, "w").write("\n".join(out) + "\n")
 print(len(out), "lines")

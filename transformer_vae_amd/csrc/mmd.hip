@@ -1008,6 +1008,9 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
         if (waste <= 1.0005) break;
     }
     p->col_splits = cs < 1 ? 1 : cs;
+#ifdef TVAE_PHASE_TIMING
+    if (getenv("TVAE_DEBUG_COL_SPLITS")) p->col_splits = atoi(getenv("TVAE_DEBUG_COL_SPLITS"));   // experiments only
+#endif
     int rpw = (p->n_pad + 511) / 512;
     if (rpw < 4) rpw = 4;
     if (rpw > 64) rpw = 64;
