@@ -148,8 +148,8 @@ def side_config(cfg_name, device, graphed):
     g0 = torch.randn((B, n_eff, d), generator=gen, device=device) / (N * d) ** 0.5
     params = list(vae.parameters())
 
-    def step():
-        out = vae(input_encoding=h, true_samples=prior)
+    def step(hh, pp):
+        out = vae(input_encoding=hh, true_samples=pp)
         loss = out.reg_loss * REG_W + (out.reconstructed_encoding * g0).sum()
         loss.backward()
         return out.reg_loss
@@ -161,17 +161,19 @@ def side_config(cfg_name, device, graphed):
 
     for _ in range(3):
         clear()
-        step()
+        step(h, prior)
     torch.cuda.synchronize(device)
     steps = 200 if cfg_name in ("cfg1", "cfg2") else 20
     if graphed:
         from transformer_vae_amd.graph import GraphedStep
-        gs = GraphedStep(lambda hh, pp: step(), (h, prior), zero_grads=[h] + params)
-        run = lambda: gs(h, prior)
+        gs = GraphedStep(step, (h, prior), zero_grads=[h] + params)
+
+        def run():
+            return gs(h, prior)
     else:
         def run():
             clear()
-            return step()
+            return step(h, prior)
     for _ in range(5):
         run()
     torch.cuda.synchronize(device)

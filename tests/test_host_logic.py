@@ -69,13 +69,16 @@ def test_mmd_scales_fold_the_reference_scaling():
 
 
 def test_oracle_is_not_imported_by_the_product():
-    import sys
-    assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules
-                   if "transformer_vae_amd" in getattr(sys.modules[m], "__name__", "")) or True
-    import inspect
-    for mod in (amd._lib, amd.autoencoders, amd.functional, amd.distributed if hasattr(amd, "distributed") else amd):
-        src = inspect.getsource(mod)
-        assert "import oracle" not in src and "from oracle" not in src
+    """oracle/ is test infrastructure: no module of the package may import it (source check over the whole package)."""
+    import glob
+    import os
+    pkg = os.path.dirname(amd.__file__)
+    files = glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True) + glob.glob(os.path.join(pkg, "csrc", "*"))
+    assert len(files) > 8
+    for f in files:
+        if os.path.isfile(f) and not f.endswith((".o", ".so")):
+            src = open(f, errors="ignore").read()
+            assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f
 
 
 def test_reg_weight_schedule_and_deferred_logs():
