@@ -401,3 +401,20 @@ def test_hip_graph_replay_matches_eager_and_oracle():
         assert relerr(vae.decoder.norm.weight.grad.cpu().numpy(), bwd["gamma"]) <= F32_TOL
     with pytest.raises(RuntimeError):
         amd.GraphedStep(step, (torch.zeros(2, 2),))
+
+
+@pytest.mark.parametrize("shape", [(0, 5, 32), (2, 0, 32)])
+def test_empty_inputs_behave_like_the_reference(shape):
+    """Empty batch / empty sequence: the reference returns empty latents and reconstructions and a NaN reg_loss
+    (mean over empty kernel matrices, autoencoders.py:130-131) without raising; parameter grads are zero."""
+    h, params, _, _ = orc.synth_inputs(2, 2, 32, 3, 11, 10, "")
+    vae = build_vae(32, 11, 3, "", params)
+    x = torch.zeros(shape, device=dev(), requires_grad=True)
+    out = vae(input_encoding=x)
+    n_eff = min(3, shape[1])
+    assert tuple(out.latent.shape) == (shape[0], n_eff, 11)
+    assert tuple(out.reconstructed_encoding.shape) == (shape[0], n_eff, 32)
+    assert out.reg_loss.dim() == 0 and bool(torch.isnan(out.reg_loss))
+    out.reconstructed_encoding.sum().backward()
+    assert x.grad.shape == x.shape
+    assert float(vae.encoder.token_to_latent.weight.grad.abs().sum()) == 0.0

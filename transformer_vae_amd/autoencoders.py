@@ -174,7 +174,8 @@ class EncoderDecoderVAE(nn.Module):
         else:
             true_samples = true_samples.reshape(latent.shape).to(latent.device)
         if latent.numel() == 0:
-            return torch.zeros((), dtype=torch.float32, device=latent.device)
+            # the reference takes the mean of empty kernel matrices (:130-131): nan, not an error
+            return torch.full((), float("nan"), dtype=torch.float32, device=latent.device)
         if self.mmd_dtype is not None:
             latent, true_samples = latent.to(self.mmd_dtype), true_samples.to(self.mmd_dtype)
         if self.mmd_scope == "global":
