@@ -164,9 +164,11 @@ def test_t5_norm_decoder_selectable():
     assert abs(float(out.reg_loss) - float(g["reg_loss"])) <= 1e-4 * abs(float(g["reg_loss"]))
 
 
-@pytest.mark.parametrize("N,D", [(37, 5), (350, 77), (1000, 200), (1536, 300), (2048, 512), (2000, 768), (1040, 1024)])
+@pytest.mark.parametrize("N,D", [(24, 2), (37, 5), (350, 77), (1000, 200), (1536, 300), (2048, 512), (2000, 768),
+                                 (520, 1000), (1040, 1024)])
 def test_mmd_every_slice_width_vs_oracle(N, D):
-    """One case per kernel instantiation (NB = 1,2,4,6,8,12,16), ragged N, against the fp64 oracle."""
+    """Kernel instantiations across the padded widths (incl. the reference's test size 2 and default 1000),
+    ragged N, against the fp64 oracle."""
     from transformer_vae_amd import functional as F
     rs = np.random.RandomState(N + D)
     z = np.tanh(rs.standard_normal((N, D))).astype(np.float32)
@@ -418,3 +420,11 @@ def test_empty_inputs_behave_like_the_reference(shape):
     out.reconstructed_encoding.sum().backward()
     assert x.grad.shape == x.shape
     assert float(vae.encoder.token_to_latent.weight.grad.abs().sum()) == 0.0
+
+
+def test_latent_size_limit_is_a_clear_error():
+    """latent_size > 1024 has no kernel instantiation: refused with a message, never computed elsewhere."""
+    from transformer_vae_amd import functional as F
+    z = torch.zeros((64, 1025), device=dev(), requires_grad=True)
+    with pytest.raises(RuntimeError, match="latent dimension 1025 not supported"):
+        F.mmd_reg_loss(z, torch.zeros((64, 1025), device=dev()), batch_size=1, n_latents=1)

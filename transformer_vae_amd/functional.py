@@ -182,7 +182,11 @@ class _MMDRegulariser(torch.autograd.Function):
         want_grad = bool(ctx.needs_input_grad[0])
         dev = za.device
         lib = _lib.lib()
-        ws = _workspace(lib.tvae_mmd_workspace_bytes(n_total, n_rows, D, int(want_grad)), dev)
+        ws_bytes = lib.tvae_mmd_workspace_bytes(n_total, n_rows, D, int(want_grad))
+        if ws_bytes < 0:
+            raise RuntimeError(f"MMD regulariser: latent dimension {D} not supported (max 1024) or empty problem "
+                               f"(n_total={n_total}, n_rows={n_rows})")
+        ws = _workspace(ws_bytes, dev)
         sums = torch.empty(3, dtype=torch.float64, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         dz = torch.empty((n_rows, D), dtype=dt, device=dev) if want_grad else None
