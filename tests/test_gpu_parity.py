@@ -428,3 +428,34 @@ def test_latent_size_limit_is_a_clear_error():
     z = torch.zeros((64, 1025), device=dev(), requires_grad=True)
     with pytest.raises(RuntimeError, match="latent dimension 1025 not supported"):
         F.mmd_reg_loss(z, torch.zeros((64, 1025), device=dev()), batch_size=1, n_latents=1)
+
+
+def test_rccl_collectives_single_rank_group():
+    """The sharded path through REAL RCCL collectives (all_gather_into_tensor on fp32/bf16 rows, all_reduce of
+    the fp64 sums) on a one-rank group: same loss and gradient as the single-device entry point."""
+    import torch.distributed as dist
+    from transformer_vae_amd import functional as F
+    from transformer_vae_amd.distributed import sharded_mmd_reg_loss
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=dev())
+    try:
+        rs = np.random.RandomState(11)
+        for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, BF16_TOL)):
+            z = torch.from_numpy(np.tanh(rs.standard_normal((640, 300))).astype(np.float32)).to(dev()).to(dtype)
+            y = torch.from_numpy(rs.standard_normal((640, 300)).astype(np.float32)).to(dev()).to(dtype)
+            za = z.clone().requires_grad_(True)
+            a = sharded_mmd_reg_loss(za, y, batch_size_local=64, n_latents=10)
+            a.backward()
+            zb = z.clone().requires_grad_(True)
+            b = F.mmd_reg_loss(zb, y, batch_size=64, n_latents=10)
+            b.backward()
+            assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 * abs(float(b.detach()))
+            assert relerr(za.grad.float().cpu().numpy(), zb.grad.float().cpu().numpy()) <= tol
+    finally:
+        dist.destroy_process_group()
