@@ -26,99 +26,10 @@
 // gradient slabs are combined by mmd_finalize_kernel in a fixed order (no atomics).
 #include <mutex>
 
-#include "tvae_common.h"
+#include "mmd_common.h"
 
 namespace tvae {
 namespace {
-
-constexpr int ROWS_PER_WG = 32;
-constexpr int TILE_P = 16;
-
-struct MmdArgs {
-    const float* cols[2];    // padded fp32 copies: [0] = z_all, [1] = y_all, row stride DPAD
-    const float* cnorm[2];   // squared norms (0 for padding rows)
-    int n_rows, n_cols, row_offset;
-    int row_blocks, col_splits, tiles_per_set, n_rows_pad;
-    int problem_base;        // first problem of this launch (0: rows = z, 1: rows = y)
-    int sums_base;           // bf16 kernels: index of this launch's first workgroup in wg_sums
-    int sym;                 // 1: the y-y problem visits each unordered pair of 32-row blocks once (weight 2)
-    float inv_d2;
-    double* wg_sums;         // [2 * row_blocks * col_splits][2]
-    double* wg_rowsum;       // [col_splits][n_rows_pad]
-    float* wg_grad;          // [col_splits][n_rows_pad][DPAD]
-};
-
-// expm1(-t) for t >= 0.  Below 1/8 a degree-6 Taylor polynomial (truncation < 1e-10);
-// otherwise the library expm1f.  The slow branch is skipped when no lane of the wave needs it.
-__device__ __forceinline__ float em1_neg(float t) {
-    const float x = -t;
-    float p = 1.f / 720.f;
-    p = fmaf(p, x, 1.f / 120.f);
-    p = fmaf(p, x, 1.f / 24.f);
-    p = fmaf(p, x, 1.f / 6.f);
-    p = fmaf(p, x, 0.5f);
-    p = fmaf(p, x, 1.f);
-    return p * x;
-}
-
-// LDS-DMA: every lane moves 16 B (dma16) or 4 B (dma4) global -> LDS at m0_base + lane*size.
-// Issued from inline asm so that hipcc neither counts it in its vmcnt bookkeeping nor drains it
-// early; M0 (the LDS base of the DMA) is written and restored inside the one statement (guide 5.7).
-// Source = wave-uniform SGPR base + per-lane 32-bit byte offset + immediate (saddr form): the tile
-// walk costs scalar adds only, and one VGPR holds the per-lane offset for the whole kernel.
-// (No instruction immediate: on LDS-DMA the offset field is added to the LDS address as well.)
-// The scalar operands go through readfirstlane: a no-op when hipcc already holds them in SGPRs, and
-// the only way to get them there when register pressure made it keep a wave-uniform value in VGPRs.
-__device__ __forceinline__ const float* uniform_ptr(const float* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ void dma16(const float* sbase, unsigned voff, unsigned lds_byte) {
-    sbase = uniform_ptr(sbase);
-    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
-}
-__device__ __forceinline__ void dma4(const float* sbase, unsigned voff, unsigned lds_byte) {
-    sbase = uniform_ptr(sbase);
-    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
-}
-
-// Two LDS-DMA instructions under one M0 set-up: the second lands 1 KiB further in LDS through the
-// instruction offset, which the hardware adds to the GLOBAL address as well -- voff_b is the caller's
-// per-lane offset with that 1 KiB already taken off.
-__device__ __forceinline__ void dma16_pair(const float* sbase, unsigned voff_a, unsigned voff_b, unsigned lds_byte) {
-    sbase = uniform_ptr(sbase);
-    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                 "global_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff_a), "v"(voff_b), "s"(sbase), "s"(lds_byte) : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// n is a constant after loop unrolling; the switch folds to one s_waitcnt
-__device__ __forceinline__ void wait_vmcnt_n(int n) {
-    switch (n) {
-        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
-        case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
-        case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
-        case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break;
-        case 15: wait_vmcnt<15>(); break; case 16: wait_vmcnt<16>(); break;
-        default: wait_vmcnt<0>(); break;
-    }
-}
 
 // LDS plan of mmd_tile_kernel.  A wave's slice of a point tile (16 points x SW floats) is stored
 // CHUNK-MAJOR and XOR-swizzled: 16-byte chunk j (4 floats) of point p lives at chunk position
@@ -418,419 +329,6 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
     }
 }
 
-// =======================================================================================
-// bf16 latents, wide dimension (DPAD = 128 KB, KB = 2..8): the same algorithm on the 16x bf16 matrix cores.
-//
-// One workgroup = 4 waves owns 32 rows (two 16-row tiles t) and walks 32-point steps (two 16-point
-// tiles pt); the feature dimension is sliced over the waves in KB blocks of 32 (one
-// v_mfma_f32_16x16x32_bf16 k-step each).  Differences from the fp32 kernel:
-//   * the four partial S' tiles (pt, t) are REDUCE-SCATTERED: wave w finishes tile (pt = w>>1, t = w&1)
-//     only (three remote partials), so the expm1 work is split over the waves instead of replicated;
-//   * E (signed) is rounded to bf16 and shared through a 2 KiB LDS buffer laid out so that every wave
-//     reads back, with one ds_read_b128 per row tile, exactly its B operand of the gradient MFMA
-//     (k = 8g + j  <->  point tile j>>2, point 4g + (j&3));
-//   * the gradient's A operand X^T comes from the SAME LDS image through ds_read_b64_tr_b16.
-// LDS image of a wave's slice (32 points x SW bf16): DMA instruction 2 s + a carries features
-// [32 s, 32 s + 32) of points [16 a, 16 a + 16) = 64 chunks of 16 B; lane l fetches chunk
-// c = (l & 3) ^ 2 ((l >> 4) & 1) of point rr = l >> 2, so every point contributes 64 contiguous bytes per
-// instruction (16 half cache lines per wave-instruction; a 32-B-per-point variant touched 32 lines and ran
-// at a fifth of the matrix-core rate), and chunk (rr, c) sits at position 4 rr + (c ^ 2 ((rr >> 2) & 1)):
-// the Gram row read (ds_read_b128) and the transposed gradient read are both bank-conflict free, each
-// instruction's 1 KiB is contiguous (in-place refill as in the fp32 kernel) and all instructions share one
-// per-lane source offset.
-// Sums and row sums use the fp32 E; only the gradient product sees the bf16 rounding of E (2^-9).
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-
-constexpr int STEP_P = 32;
-
-// Debug aid (make CXXFLAGS+=-DTVAE_PHASE_TIMING): workgroup 0 prints the cycles its wave 0 spent per phase.
-#ifdef TVAE_PHASE_TIMING
-#define PHASE_MARK(i) do { const unsigned long long _t = __builtin_readcyclecounter(); ph[i] += _t - ph_last; ph_last = _t; } while (0)
-#else
-#define PHASE_MARK(i) do { } while (0)
-#endif
-
-// RT = 16-row tiles per workgroup; with 2 RT tiles per step each of the 4 waves finishes TPW = RT / 2 of
-// them.  Production uses RT = 2 (32 rows, two workgroups per CU).  RT = 4 (64 rows: half the L2 -> LDS
-// traffic per flop, but 434 registers per lane = one wave per SIMD) was measured SLOWER at every width
-// (N = 32768: D = 768 11.3 ms vs 9.05 ms, D = 256 5.06 vs 4.49): with 16-cycle MFMAs the second resident
-// workgroup, which hides the exchange / expm1 / barrier phases, is worth more than the halved traffic.
-template <int KB, int RT, bool GRAD>
-struct Bf16Lds {
-    static constexpr int SW = 32 * KB;                       // bf16 features per wave
-    static constexpr int TPW = RT / 2;                       // S' tiles finished per wave
-    static constexpr int SLICE_B = STEP_P * SW * 2;          // bytes of one wave's slice of a 32-point step
-    static constexpr int NORM_B = 4 * SLICE_B;               // [2 buf][4 waves][32] float point norms
-    static constexpr int XCH_B = NORM_B + 2 * 4 * STEP_P * 4;
-    static constexpr int XCH_ONE_B = 2 * RT * 3 * 64 * 16;   // [tile][3 remote sources][64 lanes] float4
-    // the gradient instantiation has a second barrier per step, which also protects a single exchange buffer
-    static constexpr int XBUFS = GRAD ? 1 : (KB <= 6 ? 2 : 1);
-    static constexpr int EBUF_B = XCH_B + XBUFS * XCH_ONE_B; // [RT row tiles][64 lanes][2 point tiles] 4 x bf16
-    static constexpr int BYTES = EBUF_B + (GRAD ? RT * 64 * 16 : 0);
-    // two workgroups per CU when LDS and registers (<= 256 per lane) both allow it
-    static constexpr int WG_PER_CU = (RT == 2 && KB <= 6) ? 2 : 1;
-    static_assert(RT == 2 || RT == 4, "2 or 4 row tiles");
-    static_assert(BYTES <= 160 * 1024, "bf16 tile kernel exceeds the 160 KiB LDS");
-    static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses the exchange buffer");
-};
-
-template <int KB, int RT, bool GRAD>
-__global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
-    using L = Bf16Lds<KB, RT, GRAD>;
-    static_assert(GRAD || RT == 2, "the symmetric y-y enumeration assumes 32-row blocks");
-    constexpr int SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;     // NI: DMA instructions = 16-feature blocks per slice
-    constexpr int TPW = L::TPW, ROWS = 16 * RT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* sm = reinterpret_cast<char*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i16 = lane & 15, g = lane >> 4;
-    const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned xs_byte = smem_byte + (unsigned)(wave * L::SLICE_B);
-    const char* xs = sm + wave * L::SLICE_B;
-    // the S' tiles this wave finishes: point tile my_pt, row tiles my_t0 .. my_t0 + TPW - 1
-    const int my_pt = wave >> 1, my_t0 = (wave & 1) * TPW;
-
-    const int per_problem = a.row_blocks * a.col_splits;
-    const int problem = GRAD ? 0 : a.problem_base + (int)blockIdx.x / per_problem;
-    const int rem = (int)blockIdx.x - (problem - a.problem_base) * per_problem;
-    const int rb = rem / a.col_splits, sp = rem - rb * a.col_splits;
-    const int i0 = rb * ROWS;
-    const long long bid = (long long)a.sums_base + blockIdx.x;
-
-    // ---- the rows of this workgroup: this wave's feature slice, in registers as MFMA B operands ----
-    const bf16* rows = reinterpret_cast<const bf16*>(a.cols[problem]) + (long long)a.row_offset * DPAD;
-    const float* rnorm = a.cnorm[problem] + a.row_offset;
-    bf16x8_t zreg[RT][KB];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const int row = i0 + 16 * t + i16;
-        const bf16* zp = rows + (long long)row * DPAD + wave * SW + 8 * g;
-#pragma unroll
-        for (int s = 0; s < KB; ++s) {
-            if (row < a.n_rows) zreg[t][s] = *reinterpret_cast<const bf16x8_t*>(zp + 32 * s);
-            else zreg[t][s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    }
-    bool my_valid[TPW];
-    float rn[TPW];
-    bool all_valid = true;
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const int my_row = i0 + 16 * (my_t0 + j) + i16;
-        my_valid[j] = my_row < a.n_rows;
-        rn[j] = my_valid[j] ? rnorm[my_row] : 0.f;
-        all_valid = all_valid && my_valid[j];
-    }
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int s = 0; s < KB; ++s) asm volatile("" : "+v"(zreg[t][s]));
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) asm volatile("" : "+v"(rn[j]));
-    const bool any_invalid = __any(!all_valid);
-
-    f32x4 acc[GRAD ? NI : 1][RT];
-    if (GRAD) {
-#pragma unroll
-        for (int db = 0; db < NI; ++db)
-#pragma unroll
-            for (int t = 0; t < RT; ++t) acc[db][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    // 32-point steps; the symmetric y-y enumeration is the fp32 kernel's (one step = one block J)
-    const int nJ = a.tiles_per_set >> 1;
-    const bool sym = !GRAD && problem == 1 && a.sym;
-    const int blkI = (a.row_offset >> 5) + rb;
-    const int symA = (blkI + 1) >> 1;
-    const int symM = symA + 1 + ((nJ - 1 - blkI) >> 1);
-    const long long total = problem == 0 ? 2ll * nJ : (sym ? (long long)symM : (long long)nJ);
-    const long long base = (problem == 0 || sym) ? 0 : nJ;
-    const int sb = (int)(base + sp * total / a.col_splits);
-    const int se = (int)(base + (sp + 1) * total / a.col_splits);
-    auto actual = [&](int v) -> int {
-        if (!sym) return v;
-        const int J = v < symA ? ((blkI + 1) & 1) + 2 * v : (v == symA ? blkI : blkI + 2 * (v - symA));
-        return nJ + J;
-    };
-
-    // per-lane constants of the LDS image
-    const int dma_r = lane >> 2, dma_c = (lane & 3) ^ (2 * ((lane >> 4) & 1));
-    const unsigned dma_voff = (unsigned)(dma_r * DPAD + 8 * dma_c) * 2u;
-    const int gram_off = 16 * (4 * i16 + (g ^ (2 * ((i16 >> 2) & 1))));            // + 1024 (2 s + pt)
-    const int tq = i16 >> 2, tp = i16 & 3;
-    // transposed read of 16-feature block db of point tile pt: + 1024 (2 (db >> 1) + pt), base by parity of db
-    const int tr_off0 = 16 * (4 * (4 * g + tq) + 2 * (g & 1) + (tp >> 1)) + 8 * (tp & 1);
-    const int tr_off1 = 16 * (4 * (4 * g + tq) + 2 * ((g & 1) ^ 1) + (tp >> 1)) + 8 * (tp & 1);
-    auto tr_read = [&](int byte_off) -> s16x4_t {
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)(__attribute__((address_space(3))) char*)(sm + byte_off));
-    };
-
-    auto step_src = [&](int v) -> const bf16* {
-        const int u = actual(v);
-        const int set = u >= nJ ? 1 : 0;
-        const int p0 = (u - set * nJ) * STEP_P;
-        return reinterpret_cast<const bf16*>(a.cols[set]) + (long long)p0 * DPAD + wave * SW;
-    };
-    auto stage_norms = [&](int v, int nbuf) {
-        const int u = actual(v);
-        const int set = u >= nJ ? 1 : 0;
-        const int p0 = (u - set * nJ) * STEP_P;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(
-            smem_byte + (unsigned)(L::NORM_B + (nbuf * 4 + wave) * STEP_P * 4));
-        const float* src = uniform_ptr(a.cnorm[set] + p0);
-        if (lane < STEP_P) dma4(src, (unsigned)lane * 4u, dst);
-    };
-    const unsigned dma_voff_b = dma_voff + 16u * DPAD * 2u - 1024u;      // second point tile, see dma16_pair
-    auto dma_pair = [&](const bf16* X, int s) {       // features [32 s, 32 s + 32) of both point tiles
-        dma16_pair(reinterpret_cast<const float*>(X + 32 * s), dma_voff, dma_voff_b, xs_byte + 2048u * s);
-    };
-
-    double sum0 = 0.0, sum1 = 0.0, rowsum[TPW];
-    float f0 = 0.f, f1 = 0.f, fr[TPW];      // fp32 partials of the sums, flushed to fp64 every 8 steps
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) { rowsum[j] = 0.0; fr[j] = 0.f; }
-
-    // DMA issue order: norms(k) ... X(k) blocks 0..NI-1 ...; norms(k+1) at the top of iteration k.
-    // The last step prefetches ITSELF again (harmless, once per workgroup): no branch around any DMA, and
-    // the counted waits hold on every iteration.
-    if (sb < se) {
-        stage_norms(sb, 0);
-        const bf16* X0 = step_src(sb);
-#pragma unroll
-        for (int s = 0; s < KB; ++s) dma_pair(X0, s);
-    }
-#ifdef TVAE_PHASE_TIMING
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
-#endif
-    for (int step = sb; step < se; ++step) {
-        PHASE_MARK(5);
-        const int u = actual(step);
-        const int set = u >= nJ ? 1 : 0;
-        const int p0 = (u - set * nJ) * STEP_P;
-        const float wsym = (sym && (p0 >> 5) != blkI) ? 2.f : 1.f;
-        const int buf = (step - sb) & 1;
-        const int nstep = step + 1 < se ? step + 1 : step;
-        const bf16* Xn = step_src(nstep);
-        stage_norms(nstep, buf ^ 1);
-
-        // 1. partial Gram over the slice: S[pt][t] (16 points x 16 rows each)
-        //    The operand reads run GD k-steps ahead of their MFMAs.  Before the read of k-step s the DMAs
-        //    still allowed in flight are the younger blocks of this step, norms(k+1) and -- sum-only
-        //    instantiation, which refills block pair s right after its MFMAs -- the pairs of the next step
-        //    already issued.
-        f32x4 S[2][RT];
-#pragma unroll
-        for (int t = 0; t < RT; ++t) S[0][t] = S[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int GD = KB < 2 ? KB : 2;
-        bf16x8_t ab[KB][2];
-        auto gram_wait = [&](int sr, int issued_pairs) { wait_vmcnt_n(NI - 2 * sr - 1 + (GRAD ? 0 : 2 * issued_pairs)); };
-#pragma unroll
-        for (int s = 0; s < GD; ++s) {
-            gram_wait(s, 0);
-            ab[s][0] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * s);
-            ab[s][1] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * s + 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < KB; ++s) {
-            if (s + GD < KB) {
-                gram_wait(s + GD, s);
-                ab[s + GD][0] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + GD));
-                ab[s + GD][1] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + GD) + 1024);
-            }
-            __builtin_amdgcn_sched_barrier(0);      // keep the reads GD k-steps ahead (hipcc sinks them otherwise)
-#pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                S[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][0], zreg[t][s], S[0][t], 0, 0, 0);
-                S[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][1], zreg[t][s], S[1][t], 0, 0, 0);
-            }
-            if (!GRAD) {
-#pragma unroll
-                for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(S[0][t]), "v"(S[1][t]));
-                dma_pair(Xn, s);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(S[0][t]), "v"(S[1][t]));
-        PHASE_MARK(0);
-
-        // 2. reduce-scatter of the partials: tile q = RT pt + t goes to wave q / TPW
-        f32x4* xb = reinterpret_cast<f32x4*>(sm + L::XCH_B + (L::XBUFS == 2 ? buf * L::XCH_ONE_B : 0));
-#pragma unroll
-        for (int q = 0; q < 2 * RT; ++q) {
-            const int owner = q / TPW;
-            if (wave != owner) xb[(q * 3 + ((wave - owner - 1) & 3)) * 64 + lane] = S[q / RT][q % RT];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        PHASE_MARK(1);
-        f32x4 sv[TPW];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            // own partial: tile (pt = wave >> 1, t = (wave & 1) TPW + j)
-            sv[j] = wave == 0 ? S[0][j] : (wave == 1 ? S[0][TPW + j] : (wave == 2 ? S[1][j] : S[1][TPW + j]));
-            const int q = wave * TPW + j;
-            sv[j] += xb[(q * 3 + 0) * 64 + lane];
-            sv[j] += xb[(q * 3 + 1) * 64 + lane];
-            sv[j] += xb[(q * 3 + 2) * 64 + lane];
-        }
-        if (!GRAD && L::XBUFS == 1) {       // single exchange buffer without the E barrier: fence the reads
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-
-        // 3. E = expm1(-t) for this wave's tiles; register r <-> point p0 + 16 pt + 4 g + r, column = row i16
-        const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_B + ((buf * 4 + wave) * STEP_P + 16 * my_pt + 4 * g) * 4);
-        f32x4 e[TPW];
-        float tmax = 0.f;
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float tt = fmaxf((cn[r] + rn[j] - 2.f * sv[j][r]) * a.inv_d2, 0.f);
-                sv[j][r] = tt;
-                e[j][r] = em1_neg(tt);
-                tmax = fmaxf(tmax, tt);
-            }
-        }
-        if (__any(tmax >= 0.125f)) {
-#pragma unroll
-            for (int j = 0; j < TPW; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (sv[j][r] >= 0.125f) e[j][r] = expm1f(-sv[j][r]);
-        }
-        if (any_invalid) {
-#pragma unroll
-            for (int j = 0; j < TPW; ++j)
-                if (!my_valid[j]) e[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (p0 + STEP_P > a.n_cols) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (p0 + 16 * my_pt + 4 * g + r >= a.n_cols) {
-#pragma unroll
-                    for (int j = 0; j < TPW; ++j) e[j][r] = 0.f;
-                }
-        }
-        float es_all = 0.f;
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            const float es = (e[j][0] + e[j][1]) + (e[j][2] + e[j][3]);
-            es_all += es;
-            fr[j] += set ? -es : es;
-        }
-        if (set) f1 = fmaf(wsym, es_all, f1);
-        else f0 += es_all;
-        if (((step - sb) & 7) == 7) {
-            sum0 += (double)f0; sum1 += (double)f1;
-            f0 = f1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) { rowsum[j] += (double)fr[j]; fr[j] = 0.f; }
-        }
-
-        // 4. gradient: acc^T[d][i] += X^T[d][p] (s_p E[p][i]) over the 32 points of the step in ONE k-step
-        if (GRAD) {
-            uint2* ebuf = reinterpret_cast<uint2*>(sm + L::EBUF_B);
-            // prior columns enter the gradient with s_p = -1: flip the four sign bits of the packed values
-            const unsigned flip = set ? 0x80008000u : 0u;
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                bf16x4_t eb;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) eb[r] = (__bf16)e[j][r];
-                uint2 ebits = __builtin_bit_cast(uint2, eb);
-                ebits.x ^= flip; ebits.y ^= flip;
-                ebuf[((my_t0 + j) * 64 + lane) * 2 + my_pt] = ebits;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PHASE_MARK(2);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            PHASE_MARK(3);
-            bf16x8_t Eb[RT];
-#pragma unroll
-            for (int t = 0; t < RT; ++t) Eb[t] = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (t * 64 + lane) * 16);
-            const int tb0 = wave * L::SLICE_B + tr_off0, tb1 = wave * L::SLICE_B + tr_off1;
-            // transposed operand reads run TD blocks ahead of their MFMAs
-            constexpr int TD = NI < 3 ? NI : 3;
-            s16x4_t ga[NI][2];
-            auto grad_read = [&](int db) {
-                const int nb = ((db & 1) ? tb1 : tb0) + 2048 * (db >> 1);
-                ga[db][0] = tr_read(nb);
-                ga[db][1] = tr_read(nb + 1024);
-            };
-#pragma unroll
-            for (int db = 0; db < TD; ++db) grad_read(db);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int db = 0; db < NI; ++db) {
-                if (db + TD < NI) grad_read(db + TD);
-                __builtin_amdgcn_sched_barrier(0);  // keep the reads TD blocks ahead
-                const s16x8_t av = __builtin_shufflevector(ga[db][0], ga[db][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8_t ab2 = __builtin_bit_cast(bf16x8_t, av);
-#pragma unroll
-                for (int t = 0; t < RT; ++t)
-                    acc[db][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab2, Eb[t], acc[db][t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(acc[db][t]));
-                // features [32 s, 32 s + 32) of the step are dead after block 2 s + 1 -> refill both point tiles
-                if (db & 1) dma_pair(Xn, db >> 1);
-            }
-            PHASE_MARK(4);
-        }
-    }
-#ifdef TVAE_PHASE_TIMING
-    if (blockIdx.x == 0 && lane == 0)
-        printf("wave %d steps %d: gram %llu  xch+barrier %llu  E %llu  barrier2 %llu  grad %llu  top %llu (cycles per step)\n", wave,
-               se - sb, ph[0] / (se - sb), ph[1] / (se - sb), ph[2] / (se - sb), ph[3] / (se - sb), ph[4] / (se - sb),
-               ph[5] / (se - sb));
-#endif
-    wait_vmcnt<0>();
-    sum0 += (double)f0; sum1 += (double)f1;
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) rowsum[j] += (double)fr[j];
-
-    // ---- per-workgroup results: each wave holds the sums of ITS tiles; add the four in a fixed order ----
-    __syncthreads();
-    double* red = reinterpret_cast<double*>(sm + L::XCH_B);          // [4][2] sums, then [4 TPW][16] row sums
-    const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
-    if (lane == 0) { red[wave * 2 + 0] = w0; red[wave * 2 + 1] = w1; }
-    if (GRAD) {
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-            double rv = rowsum[j];
-            rv += __shfl_xor(rv, 16, 64);
-            rv += __shfl_xor(rv, 32, 64);
-            if (g == 0) red[8 + (wave * TPW + j) * 16 + i16] = rv;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        a.wg_sums[2 * bid + 0] = (red[0] + red[2]) + (red[4] + red[6]);
-        a.wg_sums[2 * bid + 1] = (red[1] + red[3]) + (red[5] + red[7]);
-    }
-    if (GRAD) {
-        if (tid < ROWS) {    // row 16 t + i: slot (wave * TPW + j) with t = (wave & 1) TPW + j, point tiles wave >> 1 = 0, 1
-            const int t = tid >> 4, i = tid & 15;
-            const int slot = (t / TPW) * TPW + (t % TPW);          // wave (t / TPW), j = t % TPW
-            a.wg_rowsum[(long long)sp * a.n_rows_pad + i0 + tid] = red[8 + slot * 16 + i] + red[8 + (slot + 2 * TPW) * 16 + i];
-        }
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            float* grow = a.wg_grad + ((long long)sp * a.n_rows_pad + i0 + 16 * t + i16) * DPAD + wave * SW + 4 * g;
-#pragma unroll
-            for (int db = 0; db < NI; ++db) *reinterpret_cast<f32x4*>(grow + 16 * db) = acc[GRAD ? db : 0][t];
-        }
-    }
-}
-
 // ---- prep: zero-padded copies (row stride DPAD; fp32, or bf16 for the bf16 kernels), squared norms,
 //      per-wave column sums ----
 template <typename T, typename TC>
@@ -1069,51 +567,9 @@ int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
     return fail(TVAE_ERR_ARG, "mmd: no kernel for padded dimension %d", dpad);
 }
 
-// With -DTVAE_PHASE_TIMING the environment variable TVAE_DEBUG_LDS_PAD (bytes) inflates the dynamic LDS of
-// the bf16 kernels to lower the number of resident workgroups for an experiment; otherwise both are zero.
-#ifdef TVAE_PHASE_TIMING
-constexpr int kDebugLdsPadMax = 64 * 1024;
-int debug_lds_pad() {
-    static const int pad = getenv("TVAE_DEBUG_LDS_PAD") ? atoi(getenv("TVAE_DEBUG_LDS_PAD")) : 0;
-    return pad < 0 ? 0 : (pad > kDebugLdsPadMax ? kDebugLdsPadMax : pad);
-}
-#else
-constexpr int kDebugLdsPadMax = 0;
-constexpr int debug_lds_pad() { return 0; }
-#endif
-
-template <int KB, int RT, bool GRAD>
-int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
-    constexpr int lds_bytes = Bf16Lds<KB, RT, GRAD>::BYTES;
-    static std::once_flag once;
-    static hipError_t attr_status = hipSuccess;
-    std::call_once(once, [] {
-        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes + kDebugLdsPadMax);
-    });
-    TVAE_CHECK_HIP(attr_status);
-    hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD>), dim3(nblocks), dim3(256), lds_bytes + debug_lds_pad(), s, a);
-    TVAE_CHECK_HIP(hipGetLastError());
-    return TVAE_OK;
-}
-
-template <bool GRAD>
-int launch_bf16_shape(int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
-    switch (kb) {
-        case 2: return launch_bf16<2, 2, GRAD>(a, nblocks, s);
-        case 3: return launch_bf16<3, 2, GRAD>(a, nblocks, s);
-        case 4: return launch_bf16<4, 2, GRAD>(a, nblocks, s);
-        case 5: return launch_bf16<5, 2, GRAD>(a, nblocks, s);
-        case 6: return launch_bf16<6, 2, GRAD>(a, nblocks, s);
-        case 7: return launch_bf16<7, 2, GRAD>(a, nblocks, s);
-        case 8: return launch_bf16<8, 2, GRAD>(a, nblocks, s);
-    }
-    return fail(TVAE_ERR_ARG, "mmd: no bf16 kernel for %d feature blocks", kb);
-}
-
 template <bool GRAD>
 int launch_tiles(const Plan& p, const MmdArgs& a, int nblocks, hipStream_t s) {
-    return p.bf16_tiles ? launch_bf16_shape<GRAD>(p.NB, a, nblocks, s) : launch_tile_shape<GRAD>(p.DPAD, a, nblocks, s);
+    return p.bf16_tiles ? launch_mmd_bf16(GRAD, p.NB, a, nblocks, s) : launch_tile_shape<GRAD>(p.DPAD, a, nblocks, s);
 }
 
 }  // namespace

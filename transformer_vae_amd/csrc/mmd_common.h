@@ -1,0 +1,99 @@
+// Shared pieces of the MMD tile kernels (mmd.hip: fp32 matrix cores; mmd_bf16.hip: bf16 matrix cores).
+#pragma once
+#include "tvae_common.h"
+
+namespace tvae {
+
+constexpr int ROWS_PER_WG = 32;
+constexpr int TILE_P = 16;
+
+struct MmdArgs {
+    const float* cols[2];    // padded fp32 copies: [0] = z_all, [1] = y_all, row stride DPAD
+    const float* cnorm[2];   // squared norms (0 for padding rows)
+    int n_rows, n_cols, row_offset;
+    int row_blocks, col_splits, tiles_per_set, n_rows_pad;
+    int problem_base;        // first problem of this launch (0: rows = z, 1: rows = y)
+    int sums_base;           // bf16 kernels: index of this launch's first workgroup in wg_sums
+    int sym;                 // 1: the y-y problem visits each unordered pair of 32-row blocks once (weight 2)
+    float inv_d2;
+    double* wg_sums;         // [2 * row_blocks * col_splits][2]
+    double* wg_rowsum;       // [col_splits][n_rows_pad]
+    float* wg_grad;          // [col_splits][n_rows_pad][DPAD]
+};
+
+// expm1(-t) for t >= 0.  Below 1/8 a degree-6 Taylor polynomial (truncation < 1e-10);
+// otherwise the library expm1f.  The slow branch is skipped when no lane of the wave needs it.
+__device__ __forceinline__ float em1_neg(float t) {
+    const float x = -t;
+    float p = 1.f / 720.f;
+    p = fmaf(p, x, 1.f / 120.f);
+    p = fmaf(p, x, 1.f / 24.f);
+    p = fmaf(p, x, 1.f / 6.f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.f);
+    return p * x;
+}
+
+// LDS-DMA: every lane moves 16 B (dma16) or 4 B (dma4) global -> LDS at m0_base + lane*size.
+// Issued from inline asm so that hipcc neither counts it in its vmcnt bookkeeping nor drains it
+// early; M0 (the LDS base of the DMA) is written and restored inside the one statement (guide 5.7).
+// Source = wave-uniform SGPR base + per-lane 32-bit byte offset + immediate (saddr form): the tile
+// walk costs scalar adds only, and one VGPR holds the per-lane offset for the whole kernel.
+// (No instruction immediate: on LDS-DMA the offset field is added to the LDS address as well.)
+// The scalar operands go through readfirstlane: a no-op when hipcc already holds them in SGPRs, and
+// the only way to get them there when register pressure made it keep a wave-uniform value in VGPRs.
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void dma16(const float* sbase, unsigned voff, unsigned lds_byte) {
+    sbase = uniform_ptr(sbase);
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma4(const float* sbase, unsigned voff, unsigned lds_byte) {
+    sbase = uniform_ptr(sbase);
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+// Two LDS-DMA instructions under one M0 set-up: the second lands 1 KiB further in LDS through the
+// instruction offset, which the hardware adds to the GLOBAL address as well -- voff_b is the caller's
+// per-lane offset with that 1 KiB already taken off.
+__device__ __forceinline__ void dma16_pair(const float* sbase, unsigned voff_a, unsigned voff_b, unsigned lds_byte) {
+    sbase = uniform_ptr(sbase);
+    lds_byte = __builtin_amdgcn_readfirstlane(lds_byte);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "global_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_a), "v"(voff_b), "s"(sbase), "s"(lds_byte) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// n is a constant after loop unrolling; the switch folds to one s_waitcnt
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break;
+        case 15: wait_vmcnt<15>(); break; case 16: wait_vmcnt<16>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
+// bf16 matrix-core tile kernels (mmd_bf16.hip); kb = padded dimension / 128 (2..8)
+int launch_mmd_bf16(bool grad, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
+
+}  // namespace tvae
