@@ -148,7 +148,9 @@ void choose_split(int M, int N, int K, int* splits, int* k_per_split) {
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int s = 1;
     if (tiles < 256 && K > 256) {
-        s = (int)((512 + tiles - 1) / tiles);
+        // enough workgroups for ~8 per CU: with one 32x32 accumulator per wave the kernel hides its global
+        // loads through occupancy (2-3 workgroups per CU left the weight-gradient products at 30 % MFMA-busy)
+        s = (int)((2048 + tiles - 1) / tiles);
         const int max_s = (K + 127) / 128;
         if (s > max_s) s = max_s;
         if (s > 64) s = 64;
