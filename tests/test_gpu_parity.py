@@ -459,3 +459,23 @@ def test_rccl_collectives_single_rank_group():
             assert relerr(za.grad.float().cpu().numpy(), zb.grad.float().cpu().numpy()) <= tol
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,D,dtype", [(3000, 77, torch.float32), (2500, 768, torch.float32), (1500, 1024, torch.float32),
+                                       (2500, 768, torch.bfloat16), (1500, 1000, torch.bfloat16), (2100, 300, torch.bfloat16)])
+def test_mmd_is_bitwise_deterministic(N, D, dtype):
+    """No atomics, fixed reduction orders: repeated calls on the same inputs are bit-identical (a race between
+    the in-place LDS refill and the operand reads, or between waves of the exchange, would show here)."""
+    from transformer_vae_amd import functional as F
+    gen = torch.Generator(device=dev()).manual_seed(N + D)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev())).to(dtype)
+    y = torch.randn((N, D), generator=gen, device=dev()).to(dtype)
+    ref_loss = ref_grad = None
+    for it in range(6):
+        zi = z.clone().requires_grad_(True)
+        loss = F.mmd_reg_loss(zi, y, batch_size=1, n_latents=1)
+        loss.backward()
+        if it == 0:
+            ref_loss, ref_grad = loss.detach().clone(), zi.grad.clone()
+        else:
+            assert torch.equal(loss.detach(), ref_loss) and torch.equal(zi.grad, ref_grad), it
