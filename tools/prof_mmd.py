@@ -10,7 +10,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from transformer_vae_amd import functional as F  # noqa: E402
+from transformer_vae_amd import _lib, functional as F  # noqa: E402
+
+if os.environ.get("TVAE_LIB_OVERRIDE"):          # kernel experiments: load a variant build instead
+    _lib.LIB_PATH = os.path.abspath(os.environ["TVAE_LIB_OVERRIDE"])
 
 N, D = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3

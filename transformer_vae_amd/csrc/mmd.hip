@@ -185,7 +185,11 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 #pragma unroll
         for (int i = 0; i < NB; ++i) dma16(X0 + 16 * i, dma_voff, xs_byte + 1024u * i);
     }
+#ifdef TVAE_PHASE_TIMING
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
+#endif
     for (int tile = tb; tile < te; ++tile) {
+        PHASE_MARK(5);
         const int atile = actual(tile);
         const int set = atile >= tps ? 1 : 0;
         const int p0 = (atile - set * (int)tps) * TILE_P;
@@ -221,6 +225,8 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
             av = avn;
         }
 
+        asm volatile("" ::"v"(s0), "v"(s1));
+        PHASE_MARK(0);
         // 3. exchange the slice partials through LDS (raw s_barrier: no vmcnt drain); double buffered,
         //    so one barrier per tile
         //    (WAVES == 1: narrow latents — one wave holds the whole feature dimension, nothing to exchange)
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
             }
         }
 
+        PHASE_MARK(1);
         // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
         const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g);
         f32x4 t0, t1, e0, e1;
@@ -280,6 +287,8 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 
         // 5. gradient accumulation: acc^T[d][i] += sum_p X[p][d] * (s_p E'[p][i]); block db of the tile is
         //    dead after its MFMAs -> DMA block db of the NEXT tile over it (operand reads run one block ahead)
+        asm volatile("" ::"v"(e0), "v"(e1));
+        PHASE_MARK(2);
         if (GRAD) {
             if (set) { e0 = -e0; e1 = -e1; }
             float ga[4];
@@ -300,8 +309,14 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ga[r] = gn[r];
             }
+            PHASE_MARK(4);
         }
     }
+#ifdef TVAE_PHASE_TIMING
+    if (blockIdx.x == 0 && lane == 0)
+        printf("wave %d tiles %d: gram %llu  xch+barrier %llu  E %llu  grad %llu  top %llu (timer ticks per tile)\n", wave,
+               te - tb, ph[0] / (te - tb), ph[1] / (te - tb), ph[2] / (te - tb), ph[4] / (te - tb), ph[5] / (te - tb));
+#endif
     wait_vmcnt<0>();
 
     // ---- per-workgroup results (every wave holds identical sums; wave 0 writes) ----

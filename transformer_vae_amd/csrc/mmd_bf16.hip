@@ -35,12 +35,6 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 constexpr int STEP_P = 32;
 
-// Debug aid (make CXXFLAGS+=-DTVAE_PHASE_TIMING): workgroup 0 prints the cycles its wave 0 spent per phase.
-#ifdef TVAE_PHASE_TIMING
-#define PHASE_MARK(i) do { const unsigned long long _t = __builtin_readcyclecounter(); ph[i] += _t - ph_last; ph_last = _t; } while (0)
-#else
-#define PHASE_MARK(i) do { } while (0)
-#endif
 
 // RT = 16-row tiles per workgroup; with 2 RT tiles per step each of the 4 waves finishes TPW = RT / 2 of
 // them.  Production uses RT = 2 (32 rows, two workgroups per CU).  RT = 4 (64 rows: half the L2 -> LDS

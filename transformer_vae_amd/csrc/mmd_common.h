@@ -93,6 +93,13 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
     }
 }
 
+// Debug aid (build with -DTVAE_PHASE_TIMING): workgroup 0 prints the cycles its wave 0 spent per phase.
+#ifdef TVAE_PHASE_TIMING
+#define PHASE_MARK(i) do { const unsigned long long _t = __builtin_readcyclecounter(); ph[i] += _t - ph_last; ph_last = _t; } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+
 // bf16 matrix-core tile kernels (mmd_bf16.hip); kb = padded dimension / 128 (2..8)
 int launch_mmd_bf16(bool grad, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 
