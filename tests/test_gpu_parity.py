@@ -422,12 +422,41 @@ def test_empty_inputs_behave_like_the_reference(shape):
     assert float(vae.encoder.token_to_latent.weight.grad.abs().sum()) == 0.0
 
 
-def test_latent_size_limit_is_a_clear_error():
-    """latent_size > 1024 has no kernel instantiation: refused with a message, never computed elsewhere."""
+@pytest.mark.parametrize("N,D,dtype", [(300, 1100, torch.float32), (257, 2048, torch.float32), (300, 1100, torch.bfloat16)])
+def test_mmd_latent_sizes_beyond_the_tile_kernels(N, D, dtype):
+    """latent_size > 1024 (the reference has no cap): the strip-wise route through the GEMM kernel, against the oracle."""
     from transformer_vae_amd import functional as F
-    z = torch.zeros((64, 1025), device=dev(), requires_grad=True)
-    with pytest.raises(RuntimeError, match="latent dimension 1025 not supported"):
-        F.mmd_reg_loss(z, torch.zeros((64, 1025), device=dev()), batch_size=1, n_latents=1)
+    rs = np.random.RandomState(N + D)
+    zt = torch.from_numpy(np.tanh(rs.standard_normal((N, D))).astype(np.float32)).to(dev()).to(dtype).requires_grad_(True)
+    yt = torch.from_numpy(rs.standard_normal((N, D)).astype(np.float32)).to(dev()).to(dtype)
+    reg = F.mmd_reg_loss(zt, yt, batch_size=3, n_latents=7)
+    reg.backward()
+    z64, y64 = zt.detach().double().cpu().numpy(), yt.double().cpu().numpy()
+    ref = orc.mmd_gram(y64, z64) * 7 / 3
+    gref = orc.mmd_grad_latent_rows(z64, z64, y64) * 7 / 3
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert abs(float(reg.detach()) - ref) <= F32_TOL * abs(ref), (float(reg.detach()), ref)
+    assert relerr(zt.grad.float().cpu().numpy(), gref) <= tol
+
+
+def test_mmd_wide_row_block_over_several_strips():
+    """A row block of a wide problem that spans two strips of the kernel matrix (N = 33 000 -> 960-row strips)."""
+    from transformer_vae_amd import functional as F
+    N, D, rows, off = 33000, 1030, 1000, 7000
+    gen = torch.Generator(device=dev()).manual_seed(5)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev()))
+    y = torch.randn((N, D), generator=gen, device=dev())
+    ls, gs = F.mmd_scales(100, 330, N, D)
+    zr = z[off:off + rows].clone().requires_grad_(True)
+    loss, sums = F.mmd_row_block(zr, z, y, off, ls, gs)
+    loss.backward()
+    z64, y64 = z.double().cpu().numpy(), y.double().cpu().numpy()
+    ref = np.array(orc.mmd_partial_sums(z64[off:off + rows], y64[off:off + rows], z64, y64))
+    assert np.all(np.abs(sums.cpu().numpy() - ref) <= 1e-6 * np.abs(ref)), (sums.cpu().numpy(), ref)
+    sl = slice(off + 950, off + 970)                       # rows on both sides of the strip boundary
+    gref = orc.mmd_grad_latent_rows(z64[sl], z64, y64) * (gs * N * N * D * D / 4.0)
+    got = zr.grad[950:970].double().cpu().numpy()
+    assert relerr(got, gref) <= F32_TOL
 
 
 def test_rccl_collectives_single_rank_group():

@@ -607,6 +607,8 @@ extern "C" int tvae_profile_next_mmd(void* ev_start, void* ev_stop) {
 extern "C" int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad) {
     // the dtype is not an argument here: report the larger of the two plans a call may pick
     Plan p, q;
+    if (n_total > 0 && n_rows > 0 && D > 1024 && n_total < (1ll << 30))
+        return mmd_wide_workspace_bytes(n_total, n_rows, D, want_grad != 0);
     if (n_total <= 0 || n_rows <= 0 || D <= 0 || !make_plan(n_total, n_rows, D, want_grad != 0, false, &p)) return -1;
     if (use_bf16_tiles(TVAE_BF16, D) && make_plan(n_total, n_rows, D, want_grad != 0, true, &q) && q.bytes > p.bytes)
         return q.bytes;
@@ -625,6 +627,15 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     TVAE_REQUIRE(row_offset >= 0 && row_offset + n_rows <= n_total, "mmd: row block [%lld,%lld) outside [0,%lld)",
                  (long long)row_offset, (long long)(row_offset + n_rows), (long long)n_total);
     TVAE_REQUIRE(n_total < (1ll << 30), "mmd: n_total too large");
+    if (D > 1024) {      // beyond the tile kernels' register budget: strip-wise route through the GEMM kernel
+        const hipEvent_t w0 = g_prof_start, w1 = g_prof_stop;
+        g_prof_start = g_prof_stop = nullptr;
+        if (w0) TVAE_CHECK_HIP(hipEventRecord(w0, s));
+        TVAE_PROPAGATE(mmd_wide_launch(z_all, y_all, n_total, row_offset, n_rows, D, dtype, sums3, loss, loss_scale, d_z,
+                                       grad_scale, workspace, workspace_bytes, s));
+        if (w1) TVAE_CHECK_HIP(hipEventRecord(w1, s));
+        return TVAE_OK;
+    }
     Plan p;
     TVAE_REQUIRE(make_plan(n_total, n_rows, D, d_z != nullptr, use_bf16_tiles(dtype, D), &p),
                  "mmd: latent dimension %lld not supported (max 1024)", (long long)D);

@@ -122,4 +122,10 @@ int layernorm_bwd_params(const void* dout, const void* r, const float* mean, con
 int tanh_bwd(const void* dz, const void* z, void* dpre, int64_t count, int dtype, hipStream_t s);
 int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype, hipStream_t s);
 
+// strip-wise MMD for latent sizes beyond the tile kernels (mmd_wide.hip)
+int64_t mmd_wide_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad);
+int mmd_wide_launch(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset, int64_t n_rows,
+                    int64_t D, int dtype, double* sums3, float* loss, double loss_scale, void* d_z,
+                    double grad_scale, void* workspace, int64_t workspace_bytes, hipStream_t s);
+
 }  // namespace tvae

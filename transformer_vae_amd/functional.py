@@ -184,8 +184,7 @@ class _MMDRegulariser(torch.autograd.Function):
         lib = _lib.lib()
         ws_bytes = lib.tvae_mmd_workspace_bytes(n_total, n_rows, D, int(want_grad))
         if ws_bytes < 0:
-            raise RuntimeError(f"MMD regulariser: latent dimension {D} not supported (max 1024) or empty problem "
-                               f"(n_total={n_total}, n_rows={n_rows})")
+            raise RuntimeError(f"MMD regulariser: unsupported problem size (n_total={n_total}, n_rows={n_rows}, D={D})")
         ws = _workspace(ws_bytes, dev)
         sums = torch.empty(3, dtype=torch.float64, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
