@@ -123,7 +123,9 @@ int tvae_decode_bwd(const void* d_recon, const void* latent, const void* Wd,
  *          (single GPU: pass loss_scale = n_tokens / (B * n_total^2) to get reg_loss)
  *   d_z    (n_rows, D) out, nullable: grad_scale * sum-form gradient for the local rows,
  *          complete (needs no exchange):  pass grad_scale = 4 n / (B N^2 D^2) for
- *          d reg_loss / d latent  (SURVEY.md 8a).  Written in `dtype`. */
+ *          d reg_loss / d latent  (SURVEY.md 8a).  Written in `dtype`.
+ * Any D: fused tile kernels up to 1024 (fp32-input MFMA; bf16 MFMA when dtype is TVAE_BF16 and
+ * D > 192), strip-wise through the projection GEMM beyond.  n_total < 2^30. */
 int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad);
 int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all,
                      int64_t n_total, int64_t row_offset, int64_t n_rows, int64_t D, int dtype,
