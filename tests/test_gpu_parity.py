@@ -490,7 +490,8 @@ def test_rccl_collectives_single_rank_group():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,D,dtype", [(3000, 77, torch.float32), (2500, 768, torch.float32), (1500, 1024, torch.float32),
+@pytest.mark.parametrize("N,D,dtype", [(3000, 77, torch.float32), (9000, 77, torch.float32), (2500, 768, torch.float32),
+                                       (1500, 1024, torch.float32),
                                        (2500, 768, torch.bfloat16), (1500, 1000, torch.bfloat16), (2100, 300, torch.bfloat16)])
 def test_mmd_is_bitwise_deterministic(N, D, dtype):
     """No atomics, fixed reduction orders: repeated calls on the same inputs are bit-identical (a race between
@@ -508,3 +509,46 @@ def test_mmd_is_bitwise_deterministic(N, D, dtype):
             ref_loss, ref_grad = loss.detach().clone(), zi.grad.clone()
         else:
             assert torch.equal(loss.detach(), ref_loss) and torch.equal(zi.grad, ref_grad), it
+
+
+@pytest.mark.parametrize("N,D,dtype", [(8200, 77, torch.float32), (8290, 5, torch.float32), (9001, 33, torch.float32),
+                                       (8200, 64, torch.bfloat16)])
+def test_mmd_narrow_latents_64_row_kernel_vs_oracle(N, D, dtype):
+    """Large-N narrow latents take the 64-rows-per-wave kernel (mmd_narrow.hip): loss and gradient vs the fp64 oracle."""
+    from transformer_vae_amd import functional as F
+    rs = np.random.RandomState(N + D)
+    zt = torch.from_numpy(np.tanh(rs.standard_normal((N, D))).astype(np.float32)).to(dev()).to(dtype).requires_grad_(True)
+    yt = torch.from_numpy(rs.standard_normal((N, D)).astype(np.float32)).to(dev()).to(dtype)
+    reg = F.mmd_reg_loss(zt, yt, batch_size=1, n_latents=1)
+    reg.backward()
+    z64, y64 = zt.detach().double().cpu().numpy(), yt.double().cpu().numpy()
+    ref = orc.mmd_gram(y64, z64)
+    gref = orc.mmd_grad_latent_rows(z64, z64, y64)
+    assert abs(float(reg.detach()) - ref) <= F32_TOL * abs(ref), (float(reg.detach()), ref)
+    assert relerr(zt.grad.float().cpu().numpy(), gref) <= (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+@pytest.mark.parametrize("R", [3, 5])
+def test_mmd_narrow_row_blocks_compose(R):
+    """64-row kernel, row-sharded: aligned blocks (symmetric y-y enumeration on 64-point blocks) and ragged ones."""
+    from transformer_vae_amd import functional as F
+    N, D = 12288, 40
+    gen = torch.Generator(device=dev()).manual_seed(R)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev()))
+    y = torch.randn((N, D), generator=gen, device=dev())
+    ls, gs = F.mmd_scales(64, 192, N, D)
+    zfull = z.clone().requires_grad_(True)
+    loss_full, sums_full = F.mmd_row_block(zfull, zfull, y, 0, ls, gs)
+    loss_full.backward()
+    tot = torch.zeros(3, dtype=torch.float64, device=dev())
+    bounds = [r * N // R for r in range(R + 1)]          # R = 3: multiples of 64; R = 5: not
+    for r in range(R):
+        rows = z[bounds[r]:bounds[r + 1]].clone().requires_grad_(True)
+        _, sums_r = F.mmd_row_block(rows, z, y, bounds[r], ls, gs)
+        _.backward()
+        tot += sums_r
+        assert relerr(rows.grad.cpu().numpy(), zfull.grad[bounds[r]:bounds[r + 1]].cpu().numpy()) <= 1e-6
+    assert torch.allclose(tot, sums_full, rtol=1e-7, atol=0)
+    z64, y64 = z.double().cpu().numpy(), y.double().cpu().numpy()
+    ref = orc.mmd_gram(y64, z64) * 192 / 64
+    assert abs(float(loss_full.detach()) - ref) <= F32_TOL * abs(ref)

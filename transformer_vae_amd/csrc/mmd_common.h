@@ -102,5 +102,7 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 
 // bf16 matrix-core tile kernels (mmd_bf16.hip); kb = padded dimension / 128 (2..8)
 int launch_mmd_bf16(bool grad, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
+// fp32 kernel for narrow latents, 64 rows per single-wave workgroup (mmd_narrow.hip); nb = padded dimension / 16 (1..5)
+int launch_mmd_narrow(bool grad, int nb, const MmdArgs& a, int nblocks, hipStream_t s);
 
 }  // namespace tvae
