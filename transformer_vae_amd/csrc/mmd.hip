@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         }
         rn[t] = valid_i[t] ? rnorm[row] : 0.f;
     }
+    const bool any_invalid = __any(!(valid_i[0] && valid_i[1]));
     // Retire these loads BEFORE the loop: otherwise hipcc must assume them pending at the loop header
     // and waits vmcnt(0) at their first use in every iteration, draining the DMA it cannot see.
 #pragma unroll
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 
     double sum0 = 0.0, sum1 = 0.0;     // per-lane partial of sum E over set 0 / set 1
     double rowsum0 = 0.0, rowsum1 = 0.0;  // signed row sums R for the two 16-row groups
+    float f0 = 0.f, f1 = 0.f, fr0 = 0.f, fr1 = 0.f;   // their fp32 partials, flushed to fp64 every 8 tiles
 
     // DMA issue order per tile k: norms(k) ... X(k) blocks 0..NB-1 ... ; norms(k+1) goes out at the top of
     // iteration k.  The counted waits below rely on exactly this order.
@@ -195,10 +197,11 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         const int p0 = (atile - set * (int)tps) * TILE_P;
         const float wsym = (sym && (p0 >> 5) != blkI) ? 2.f : 1.f;
         const int buf = (tile - tb) & 1;
-        const bool has_next = tile + 1 < te;
-        const float* Xn = tile_src(has_next ? tile + 1 : tile);
-        if (has_next) stage_norms(tile + 1, buf ^ 1);
-        else wait_vmcnt<0>();   // last tile: fewer younger DMAs exist than the counted waits assume -> drain
+        // the last tile prefetches ITSELF again (harmless, once per workgroup): no DMA sits behind a branch
+        // and the counted waits below hold on every iteration
+        const int ntile = tile + 1 < te ? tile + 1 : tile;
+        const float* Xn = tile_src(ntile);
+        stage_norms(ntile, buf ^ 1);
 
         // 1+2. partial Gram over the slice: S'[p][i], p = point (A rows), i = our rows (B columns).
         //      Before the read of block m: all but the (younger) DMAs still allowed in flight have landed.
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
             if (!GRAD) {
                 // sum-only: block m is dead once its MFMAs are issued -> refill it with the next tile
                 asm volatile("" ::"v"(s0), "v"(s1));
-                if (has_next) dma16(Xn + 16 * m, dma_voff, xs_byte + 1024u * m);
+                dma16(Xn + 16 * m, dma_voff, xs_byte + 1024u * m);
             }
             av = avn;
         }
@@ -266,8 +269,10 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
                 if (t1[r] >= 0.125f) e1[r] = expm1f(-t1[r]);
             }
         }
-        if (!valid_i[0]) e0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!valid_i[1]) e1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (any_invalid) {
+            if (!valid_i[0]) e0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!valid_i[1]) e1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (p0 + TILE_P > a.n_cols) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -276,13 +281,17 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         const float es0 = (e0[0] + e0[1]) + (e0[2] + e0[3]);
         const float es1 = (e1[0] + e1[1]) + (e1[2] + e1[3]);
         if (set) {
-            sum1 += (double)(wsym * (es0 + es1));
-            rowsum0 -= (double)es0;
-            rowsum1 -= (double)es1;
+            f1 = fmaf(wsym, es0 + es1, f1);
+            fr0 -= es0;
+            fr1 -= es1;
         } else {
-            sum0 += (double)(es0 + es1);
-            rowsum0 += (double)es0;
-            rowsum1 += (double)es1;
+            f0 += es0 + es1;
+            fr0 += es0;
+            fr1 += es1;
+        }
+        if (((tile - tb) & 7) == 7) {
+            sum0 += (double)f0; sum1 += (double)f1; rowsum0 += (double)fr0; rowsum1 += (double)fr1;
+            f0 = f1 = fr0 = fr1 = 0.f;
         }
 
         // 5. gradient accumulation: acc^T[d][i] += sum_p X[p][d] * (s_p E'[p][i]); block db of the tile is
@@ -290,7 +299,12 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         asm volatile("" ::"v"(e0), "v"(e1));
         PHASE_MARK(2);
         if (GRAD) {
-            if (set) { e0 = -e0; e1 = -e1; }
+            const unsigned flip = set ? 0x80000000u : 0u;      // prior columns enter with s_p = -1
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e0[r] = __uint_as_float(__float_as_uint(e0[r]) ^ flip);
+                e1[r] = __uint_as_float(__float_as_uint(e1[r]) ^ flip);
+            }
             float ga[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) ga[r] = xs[grad_off[r]];
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
                     acc[db][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[r], e1[r], acc[db][1], 0, 0, 0);
                 }
                 asm volatile("" ::"v"(acc[db][0]), "v"(acc[db][1]));   // MFMAs of block db are issued before its refill
-                if (has_next) dma16(Xn + 16 * db, dma_voff, xs_byte + 1024u * db);
+                dma16(Xn + 16 * db, dma_voff, xs_byte + 1024u * db);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ga[r] = gn[r];
             }
@@ -318,6 +332,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
                te - tb, ph[0] / (te - tb), ph[1] / (te - tb), ph[2] / (te - tb), ph[4] / (te - tb), ph[5] / (te - tb));
 #endif
     wait_vmcnt<0>();
+    sum0 += (double)f0; sum1 += (double)f1; rowsum0 += (double)fr0; rowsum1 += (double)fr1;
 
     // ---- per-workgroup results (every wave holds identical sums; wave 0 writes) ----
     const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
