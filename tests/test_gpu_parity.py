@@ -552,3 +552,34 @@ def test_mmd_narrow_row_blocks_compose(R):
     z64, y64 = z.double().cpu().numpy(), y.double().cpu().numpy()
     ref = orc.mmd_gram(y64, z64) * 192 / 64
     assert abs(float(loss_full.detach()) - ref) <= F32_TOL * abs(ref)
+
+
+def _mmd_fp64_on_gpu(z, y, chunk=4096):
+    """Chunked fp64 evaluation of the MMD on the GPU (torch): the ground truth at sizes the CPU oracle cannot reach."""
+    D = z.shape[1]
+
+    def esum(a, b):
+        a64, b64 = a.double(), b.double()
+        na, nb = (a64 * a64).sum(1), (b64 * b64).sum(1)
+        tot = torch.zeros((), dtype=torch.float64, device=z.device)
+        for r0 in range(0, a.shape[0], chunk):
+            t = (na[r0:r0 + chunk, None] + nb[None, :] - 2.0 * (a64[r0:r0 + chunk] @ b64.T)) / float(D * D)
+            tot += torch.expm1(-t.clamp_min(0)).sum()
+        return tot
+
+    return float((esum(y, y) + esum(z, z) - 2 * esum(z, y)) / float(z.shape[0]) ** 2)
+
+
+@pytest.mark.parametrize("N,D,dtype", [(32768, 768, torch.float32), (24000, 1024, torch.float32), (40000, 77, torch.float32),
+                                       (32768, 768, torch.bfloat16), (6000, 1500, torch.float32)])
+def test_mmd_loss_at_scale_against_fp64(N, D, dtype):
+    """At large N and D the three kernel sums are ~3000x the MMD they combine to (the terms linear in
+    |a-b|^2 cancel analytically).  The kernels accumulate the second-order part and add the linear part in
+    closed form: the loss must match fp64 to 1e-6 here (accumulating E itself gave 1.6e-5 at N=32768, D=768)."""
+    from transformer_vae_amd import functional as F
+    gen = torch.Generator(device=dev()).manual_seed(N + D)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev())).to(dtype)
+    y = torch.randn((N, D), generator=gen, device=dev()).to(dtype)
+    ref = _mmd_fp64_on_gpu(z, y)
+    loss = F.mmd_reg_loss(z.clone().requires_grad_(True), y, batch_size=1, n_latents=1)
+    assert abs(float(loss.detach()) - ref) <= 1e-6 * abs(ref), (float(loss.detach()), ref)

@@ -252,42 +252,52 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         PHASE_MARK(1);
         // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
         const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g);
-        f32x4 t0, t1, e0, e1;
+        f32x4 t0, t1, e0, e1, q0, q1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             t0[r] = fmaxf((cn[r] + rn[0] - 2.f * s0[r]) * a.inv_d2, 0.f);
             t1[r] = fmaxf((cn[r] + rn[1] - 2.f * s1[r]) * a.inv_d2, 0.f);
-            e0[r] = em1_neg(t0[r]);
-            e1[r] = em1_neg(t1[r]);
         }
         const float tmax = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])),
                                  fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
-        if (__any(tmax >= 0.125f)) {
+        if (!__any(tmax >= EM1_TINY)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (t0[r] >= 0.125f) e0[r] = expm1f(-t0[r]);
-                if (t1[r] >= 0.125f) e1[r] = expm1f(-t1[r]);
+                { const EQ v_ = em1_split_tiny(t0[r]); e0[r] = v_.e; q0[r] = v_.q; }
+                { const EQ v_ = em1_split_tiny(t1[r]); e1[r] = v_.e; q1[r] = v_.q; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                { const EQ v_ = em1_split(t0[r]); e0[r] = v_.e; q0[r] = v_.q; }
+                { const EQ v_ = em1_split(t1[r]); e1[r] = v_.e; q1[r] = v_.q; }
+            }
+            if (__any(tmax >= EM1_POLY_MAX)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (t0[r] >= EM1_POLY_MAX) { e0[r] = expm1f(-t0[r]); q0[r] = e0[r] + t0[r]; }
+                    if (t1[r] >= EM1_POLY_MAX) { e1[r] = expm1f(-t1[r]); q1[r] = e1[r] + t1[r]; }
+                }
             }
         }
         if (any_invalid) {
-            if (!valid_i[0]) e0 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!valid_i[1]) e1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!valid_i[0]) { e0 = f32x4{0.f, 0.f, 0.f, 0.f}; q0 = e0; }
+            if (!valid_i[1]) { e1 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = e1; }
         }
         if (p0 + TILE_P > a.n_cols) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (p0 + 4 * g + r >= a.n_cols) { e0[r] = 0.f; e1[r] = 0.f; }
+                if (p0 + 4 * g + r >= a.n_cols) { e0[r] = 0.f; e1[r] = 0.f; q0[r] = 0.f; q1[r] = 0.f; }
         }
-        const float es0 = (e0[0] + e0[1]) + (e0[2] + e0[3]);
-        const float es1 = (e1[0] + e1[1]) + (e1[2] + e1[3]);
-        if (set) {
-            f1 = fmaf(wsym, es0 + es1, f1);
-            fr0 -= es0;
-            fr1 -= es1;
-        } else {
-            f0 += es0 + es1;
-            fr0 += es0;
-            fr1 += es1;
+        // sums carry Q (the linear part is added in closed form by the finalize kernel); row sums carry E
+        const float qs = ((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+        if (set) f1 = fmaf(wsym, qs, f1);
+        else f0 += qs;
+        if (GRAD) {
+            const float es0 = (e0[0] + e0[1]) + (e0[2] + e0[3]);
+            const float es1 = (e1[0] + e1[1]) + (e1[2] + e1[3]);
+            fr0 += set ? -es0 : es0;
+            fr1 += set ? -es1 : es1;
         }
         if (((tile - tb) & 7) == 7) {
             sum0 += (double)f0; sum1 += (double)f1; rowsum0 += (double)fr0; rowsum1 += (double)fr1;
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                                                        int n_pad, int D, int DPAD, TC* __restrict__ zp,
                                                        TC* __restrict__ yp, float* __restrict__ zn,
                                                        float* __restrict__ yn, float* __restrict__ colpart,
-                                                       int rows_per_wave, int nwaves) {
+                                                       int rows_per_wave, int nwaves, int lo, int hi, int nw0, int nw1) {
     const int lane = threadIdx.x & 63;
     const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wg >= nwaves) return;
@@ -378,8 +388,12 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
     float csum[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) csum[j] = 0.f;
-    const int r0 = wg * rows_per_wave;
-    const int r1 = min(n_pad, r0 + rows_per_wave);
+    // rows are cut into [0, lo), [lo, hi), [hi, n_pad) -- the local row range of this call is [lo, hi) -- and
+    // each segment into chunks of rows_per_wave: waves nw0 .. nw0 + nw1 - 1 hold exactly the local rows
+    int r0, r1;
+    if (wg < nw0) { r0 = wg * rows_per_wave; r1 = min(lo, r0 + rows_per_wave); }
+    else if (wg < nw0 + nw1) { r0 = lo + (wg - nw0) * rows_per_wave; r1 = min(hi, r0 + rows_per_wave); }
+    else { r0 = hi + (wg - nw0 - nw1) * rows_per_wave; r1 = min(n_pad, r0 + rows_per_wave); }
     for (int row = r0; row < r1; ++row) {
         float sq = 0.f;
 #pragma unroll
@@ -401,26 +415,43 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
         if (j < NJ && lane + 64 * j < DPAD) cp[lane + 64 * j] = csum[j];
 }
 
-// shift[c] = sum_rows z[.,c] - sum_rows y[.,c]  (fp64 accumulate over the per-wave partials).
-// One workgroup per 64 columns; 16 row-lanes stride over the partials, then a fixed-order LDS reduction.
-__global__ __launch_bounds__(1024) void mmd_shift_kernel(const float* __restrict__ colpart, int nwaves, int DPAD,
-                                                         float* __restrict__ shift) {
-    __shared__ double red[16][64];
+// Column moments from the per-wave partials (fp64 accumulate, fixed order):
+//   shift[c] = sum_rows z[.,c] - sum_rows y[.,c]                       (mean-shift term of the gradient)
+//   dots[block][3] = partial dot products over this block's 64 columns of
+//       <c_z^local, c_z>, <c_z^local, c_y>, <c_y^local, c_y>,   c = column sums, local = rows of this call
+// (the closed-form linear part of the three sums, see em1_split in mmd_common.h).
+// One workgroup per 64 columns; 16 row-lanes stride over the partials, then fixed-order LDS reductions.
+__global__ __launch_bounds__(1024) void mmd_moments_kernel(const float* __restrict__ colpart, int nwaves, int nw0, int nw1,
+                                                           int DPAD, float* __restrict__ shift, double* __restrict__ dots) {
+    __shared__ double red[4][16][64];
+    __shared__ double prod[3][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
-    double s = 0.0;
+    double cz = 0.0, cy = 0.0, czl = 0.0, cyl = 0.0;
     if (c < DPAD) {
-#pragma unroll 4
-        for (int w = ry; w < nwaves; w += 16)
-            s += (double)colpart[(long long)w * DPAD + c] - (double)colpart[((long long)nwaves + w) * DPAD + c];
+        for (int w = ry; w < nwaves; w += 16) {
+            const double vz = (double)colpart[(long long)w * DPAD + c];
+            const double vy = (double)colpart[((long long)nwaves + w) * DPAD + c];
+            cz += vz; cy += vy;
+            if (w >= nw0 && w < nw0 + nw1) { czl += vz; cyl += vy; }
+        }
     }
-    red[ry][cx] = s;
+    red[0][ry][cx] = cz; red[1][ry][cx] = cy; red[2][ry][cx] = czl; red[3][ry][cx] = cyl;
     __syncthreads();
-    if (ry == 0 && c < DPAD) {
-        double t = 0.0;
+    if (ry == 0) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][cx];
-        shift[c] = (float)t;
+        for (int k = 0; k < 16; ++k) {
+            t[0] += red[0][k][cx]; t[1] += red[1][k][cx]; t[2] += red[2][k][cx]; t[3] += red[3][k][cx];
+        }
+        if (c < DPAD) shift[c] = (float)(t[0] - t[1]);
+        prod[0][cx] = t[2] * t[0]; prod[1][cx] = t[2] * t[1]; prod[2][cx] = t[3] * t[1];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double d = 0.0;
+        for (int k = 0; k < 64; ++k) d += prod[threadIdx.x][k];
+        dots[blockIdx.x * 3 + threadIdx.x] = d;
     }
 }
 
@@ -430,6 +461,8 @@ struct FinalArgs {
     int col_splits, n_rows, n_rows_pad, row_offset, D, DPAD;
     double* sums3; float* loss; double loss_scale; double grad_scale;
     void* d_z;
+    // closed-form linear part: squared norms of all points, the local rows, the column-moment dot products
+    const float* zn; const float* yn; int n_total; const double* dots; int ndots;
 };
 
 template <typename T, typename TC>
@@ -453,9 +486,34 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
             }
             __syncthreads();
         }
+        const double qzz = red[0][0], qzy = red[1][0], qyy = red[2][0];     // sums of Q = E + t (second order)
+        __syncthreads();
+        // linear part in closed form:  sum_{i local, j} |a_i - b_j|^2 = N A_loc + n_loc A_all - 2 <c_loc, c_all>
+        double az = 0.0, ay = 0.0, azl = 0.0, ayl = 0.0;
+        for (int i = tid; i < f.n_total; i += 256) {
+            const double vz = (double)f.zn[i], vy = (double)f.yn[i];
+            az += vz; ay += vy;
+            if (i >= f.row_offset && i < f.row_offset + f.n_rows) { azl += vz; ayl += vy; }
+        }
+        __shared__ double red4[4][256];
+        red4[0][tid] = az; red4[1][tid] = ay; red4[2][tid] = azl; red4[3][tid] = ayl;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) red4[k][tid] += red4[k][tid + o];
+            }
+            __syncthreads();
+        }
         if (tid == 0) {
-            f.sums3[0] = red[0][0]; f.sums3[1] = red[1][0]; f.sums3[2] = red[2][0];
-            if (f.loss) *f.loss = (float)(f.loss_scale * (red[2][0] + red[0][0] - 2.0 * red[1][0]));
+            double dzz = 0.0, dzy = 0.0, dyy = 0.0;
+            for (int k = 0; k < f.ndots; ++k) { dzz += f.dots[3 * k]; dzy += f.dots[3 * k + 1]; dyy += f.dots[3 * k + 2]; }
+            const double N = (double)f.n_total, nl = (double)f.n_rows, inv = 1.0 / ((double)f.D * (double)f.D);
+            const double szz = qzz - (N * red4[2][0] + nl * red4[0][0] - 2.0 * dzz) * inv;
+            const double szy = qzy - (N * red4[2][0] + nl * red4[1][0] - 2.0 * dzy) * inv;
+            const double syy = qyy - (N * red4[3][0] + nl * red4[1][0] - 2.0 * dyy) * inv;
+            f.sums3[0] = szz; f.sums3[1] = szy; f.sums3[2] = syy;
+            if (f.loss) *f.loss = (float)(f.loss_scale * (syy + szz - 2.0 * szy));
         }
     }
     if (!f.d_z) return;
@@ -481,7 +539,7 @@ struct Plan {
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
-    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_sums, off_rowsum, off_grad, bytes;
+    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, bytes;
 };
 
 // (padded dimension, waves per workgroup, 16-column blocks per wave); DPAD = WAVES * 16 * NB
@@ -553,7 +611,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     if (rpw < 4) rpw = 4;
     if (rpw > 64) rpw = 64;
     p->rows_per_wave = rpw;
-    p->nwaves = (p->n_pad + rpw - 1) / rpw;
+    p->nwaves = (p->n_pad + rpw - 1) / rpw + 2;       // upper bound: the row range of a call adds two chunk ends
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
     const int copy_elt = bf16_tiles ? 2 : 4;
@@ -563,6 +621,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     p->off_yn = take((int64_t)p->n_pad * 4);
     p->off_colpart = take((int64_t)2 * p->nwaves * p->DPAD * 4);
     p->off_shift = take((int64_t)p->DPAD * 4);
+    p->off_dots = take((int64_t)((p->DPAD + 63) / 64) * 3 * 8);
     p->off_sums = take((int64_t)(2 * p->row_blocks + p->row_blocks_g) * p->col_splits * 2 * 8);
     p->off_rowsum = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * 8 : 0);
     p->off_grad = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * p->DPAD * 4 : 0);
@@ -678,24 +737,29 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     float* colpart = reinterpret_cast<float*>(ws + p.off_colpart);
     float* shift = reinterpret_cast<float*>(ws + p.off_shift);
 
-    dim3 pgrid((p.nwaves + 3) / 4, 2);
+    // row chunks of the prep pass: [0, lo) | [lo, hi) = this call's rows | [hi, n_pad)
+    const int rpw = p.rows_per_wave;
+    const int lo = (int)row_offset, hi = (int)(row_offset + n_rows);
+    const int nw0 = (lo + rpw - 1) / rpw, nw1 = (hi - lo + rpw - 1) / rpw, nw2 = (p.n_pad - hi + rpw - 1) / rpw;
+    const int nwaves = nw0 + nw1 + nw2;          // <= p.nwaves (the plan's bound)
+    dim3 pgrid((nwaves + 3) / 4, 2);
     if (dtype == TVAE_F32)
         hipLaunchKernelGGL((mmd_prep_kernel<float, float>), pgrid, dim3(256), 0, s, (const float*)z_all,
                            (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, p.rows_per_wave, p.nwaves);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1);
     else if (!p.bf16_tiles)
         hipLaunchKernelGGL((mmd_prep_kernel<bf16, float>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
                            (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, p.rows_per_wave, p.nwaves);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1);
     else
         hipLaunchKernelGGL((mmd_prep_kernel<bf16, bf16>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
                            (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (bf16*)zp, (bf16*)yp, zn, yn,
-                           colpart, p.rows_per_wave, p.nwaves);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1);
     TVAE_CHECK_HIP(hipGetLastError());
-    if (d_z) {
-        hipLaunchKernelGGL(mmd_shift_kernel, dim3((p.DPAD + 63) / 64), dim3(1024), 0, s, colpart, p.nwaves, p.DPAD, shift);
-        TVAE_CHECK_HIP(hipGetLastError());
-    }
+    double* dots = reinterpret_cast<double*>(ws + p.off_dots);
+    const int ndots = (p.DPAD + 63) / 64;
+    hipLaunchKernelGGL(mmd_moments_kernel, dim3(ndots), dim3(1024), 0, s, colpart, nwaves, nw0, nw1, p.DPAD, shift, dots);
+    TVAE_CHECK_HIP(hipGetLastError());
 
     MmdArgs a;
     a.cols[0] = (const float*)zp; a.cols[1] = (const float*)yp; a.cnorm[0] = zn; a.cnorm[1] = yn;
@@ -730,6 +794,7 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     f.col_splits = p.col_splits; f.n_rows = (int)n_rows; f.n_rows_pad = p.n_rows_pad; f.row_offset = (int)row_offset;
     f.D = (int)D; f.DPAD = p.DPAD; f.sums3 = sums3; f.loss = loss; f.loss_scale = loss_scale; f.grad_scale = grad_scale;
     f.d_z = d_z;
+    f.zn = zn; f.yn = yn; f.n_total = (int)n_total; f.dots = dots; f.ndots = ndots;
     long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
     if (fb > 4096) fb = 4096;
     if (fb < 1) fb = 1;

@@ -270,47 +270,59 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
 
         // 3. E = expm1(-t) for this wave's tiles; register r <-> point p0 + 16 pt + 4 g + r, column = row i16
         const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_B + ((buf * 4 + wave) * STEP_P + 16 * my_pt + 4 * g) * 4);
-        f32x4 e[TPW];
+        f32x4 e[TPW], q[TPW];
         float tmax = 0.f;
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) {
+        for (int j = 0; j < TPW; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float tt = fmaxf((cn[r] + rn[j] - 2.f * sv[j][r]) * a.inv_d2, 0.f);
                 sv[j][r] = tt;
-                e[j][r] = em1_neg(tt);
                 tmax = fmaxf(tmax, tt);
             }
-        }
-        if (__any(tmax >= 0.125f)) {
+        if (!__any(tmax >= EM1_TINY)) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (sv[j][r] >= 0.125f) e[j][r] = expm1f(-sv[j][r]);
+                for (int r = 0; r < 4; ++r) { const EQ v_ = em1_split_tiny(sv[j][r]); e[j][r] = v_.e; q[j][r] = v_.q; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const EQ v_ = em1_split(sv[j][r]); e[j][r] = v_.e; q[j][r] = v_.q; }
+            if (__any(tmax >= EM1_POLY_MAX)) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (sv[j][r] >= EM1_POLY_MAX) { e[j][r] = expm1f(-sv[j][r]); q[j][r] = e[j][r] + sv[j][r]; }
+            }
         }
         if (any_invalid) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
-                if (!my_valid[j]) e[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!my_valid[j]) { e[j] = f32x4{0.f, 0.f, 0.f, 0.f}; q[j] = e[j]; }
         }
         if (p0 + STEP_P > a.n_cols) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (p0 + 16 * my_pt + 4 * g + r >= a.n_cols) {
 #pragma unroll
-                    for (int j = 0; j < TPW; ++j) e[j][r] = 0.f;
+                    for (int j = 0; j < TPW; ++j) { e[j][r] = 0.f; q[j][r] = 0.f; }
                 }
         }
-        float es_all = 0.f;
+        // sums carry Q (linear part: closed form in the finalize kernel); row sums carry E
+        float qs_all = 0.f;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-            const float es = (e[j][0] + e[j][1]) + (e[j][2] + e[j][3]);
-            es_all += es;
-            fr[j] += set ? -es : es;
+            qs_all += (q[j][0] + q[j][1]) + (q[j][2] + q[j][3]);
+            if (GRAD) {
+                const float es = (e[j][0] + e[j][1]) + (e[j][2] + e[j][3]);
+                fr[j] += set ? -es : es;
+            }
         }
-        if (set) f1 = fmaf(wsym, es_all, f1);
-        else f0 += es_all;
+        if (set) f1 = fmaf(wsym, qs_all, f1);
+        else f0 += qs_all;
         if (((step - sb) & 7) == 7) {
             sum0 += (double)f0; sum1 += (double)f1;
             f0 = f1 = 0.f;

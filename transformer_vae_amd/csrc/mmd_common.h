@@ -23,16 +23,35 @@ struct MmdArgs {
 
 // expm1(-t) for t >= 0.  Below 1/8 a degree-6 Taylor polynomial (truncation < 1e-10);
 // otherwise the library expm1f.  The slow branch is skipped when no lane of the wave needs it.
-__device__ __forceinline__ float em1_neg(float t) {
+// E = expm1(-t) = -t + Q(t),  Q(t) = t^2/2 - t^3/6 + ... >= 0.
+// The kernels need E (gradient, row sums) AND Q: in  sum E(y,y) + sum E(z,z) - 2 sum E(y,z)  the terms linear
+// in t cancel ANALYTICALLY down to 2 |sum z - sum y|^2 / D^2, so accumulating E leaves a result ~1/D of the
+// summands (measured: the three fp32-accumulated sums carry relative biases that differ by ~2e-9, which is
+// 1.5e-5 of the MMD at D = 768, N = 32 768).  The tile kernels therefore accumulate Q, and the finalize
+// kernels add the linear part in closed form from norms and column sums in fp64.
+// x = -t;  Q = x^2 r(x),  r(x) = 1/2 + x/6 + x^2/24 + x^3/120 + x^4/720  (|t| < 1/8: truncation < 1e-10 of Q)
+struct EQ { float e, q; };
+__device__ __forceinline__ EQ em1_split(float t) {
     const float x = -t;
     float p = 1.f / 720.f;
     p = fmaf(p, x, 1.f / 120.f);
     p = fmaf(p, x, 1.f / 24.f);
     p = fmaf(p, x, 1.f / 6.f);
     p = fmaf(p, x, 0.5f);
-    p = fmaf(p, x, 1.f);
-    return p * x;
+    const float px = p * x;
+    return EQ{fmaf(px, x, x), px * x};
 }
+// 0 <= t < 1/256 (wide latents: t ~ 1/D): r(x) = 1/2 + x/6 + x^2/24, truncation < 1e-9 of Q
+__device__ __forceinline__ EQ em1_split_tiny(float t) {
+    const float x = -t;
+    float p = 1.f / 24.f;
+    p = fmaf(p, x, 1.f / 6.f);
+    p = fmaf(p, x, 0.5f);
+    const float px = p * x;
+    return EQ{fmaf(px, x, x), px * x};
+}
+constexpr float EM1_TINY = 1.f / 256.f;
+constexpr float EM1_POLY_MAX = 0.125f;     // beyond: library exp; |E| >= 0.1175 there, so Q = E + t keeps 20 bits
 
 // LDS-DMA: every lane moves 16 B (dma16) or 4 B (dma4) global -> LDS at m0_base + lane*size.
 // Issued from inline asm so that hipcc neither counts it in its vmcnt bookkeeping nor drains it

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64, 2) void mmd_narrow_kernel(MmdArgs a) {
 
         // 2. E = expm1(-t)
         const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + NORM_OFF + buf * TILE_P + 4 * g);
-        f32x4 e[NRT];
+        f32x4 e[NRT], q[NRT];
         float tmax = 0.f;
 #pragma unroll
         for (int t = 0; t < NRT; ++t)
@@ -169,42 +169,57 @@ __global__ __launch_bounds__(64, 2) void mmd_narrow_kernel(MmdArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const float tt = fmaxf((cn[r] + rn[t] - 2.f * S[t][r]) * a.inv_d2, 0.f);
                 S[t][r] = tt;
-                e[t][r] = em1_neg(tt);
                 tmax = fmaxf(tmax, tt);
             }
-        if (__any(tmax >= 0.125f)) {
-            // beyond the polynomial's range |E| >= 0.1175, so exp(-t) - 1 loses at most 3 bits (relative error
-            // < 1e-6); sixteen inlined expm1f bodies would not fit the register budget of this kernel
+        if (!__any(tmax >= EM1_TINY)) {
 #pragma unroll
             for (int t = 0; t < NRT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ex = expf(-S[t][r]) - 1.f;
-                    e[t][r] = S[t][r] >= 0.125f ? ex : e[t][r];
-                }
+                for (int r = 0; r < 4; ++r) { const EQ v_ = em1_split_tiny(S[t][r]); e[t][r] = v_.e; q[t][r] = v_.q; }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NRT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const EQ v_ = em1_split(S[t][r]); e[t][r] = v_.e; q[t][r] = v_.q; }
+            if (__any(tmax >= EM1_POLY_MAX)) {
+                // |E| >= 0.1175 here, so exp(-t) - 1 loses at most 3 bits (relative error < 1e-6); sixteen
+                // inlined expm1f bodies would not fit the register budget of this kernel
+#pragma unroll
+                for (int t = 0; t < NRT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float ex = expf(-S[t][r]) - 1.f;
+                        const bool big = S[t][r] >= EM1_POLY_MAX;
+                        e[t][r] = big ? ex : e[t][r];
+                        q[t][r] = big ? ex + S[t][r] : q[t][r];
+                    }
+            }
         }
         if (any_invalid) {
 #pragma unroll
             for (int t = 0; t < NRT; ++t)
-                if (!valid_i[t]) e[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!valid_i[t]) { e[t] = f32x4{0.f, 0.f, 0.f, 0.f}; q[t] = e[t]; }
         }
         if (p0 + TILE_P > a.n_cols) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (p0 + 4 * g + r >= a.n_cols) {
 #pragma unroll
-                    for (int t = 0; t < NRT; ++t) e[t][r] = 0.f;
+                    for (int t = 0; t < NRT; ++t) { e[t][r] = 0.f; q[t][r] = 0.f; }
                 }
         }
-        float es_all = 0.f;
+        // sums carry Q (linear part: closed form in the finalize kernel); row sums carry E
+        float qs_all = 0.f;
 #pragma unroll
         for (int t = 0; t < NRT; ++t) {
-            const float es = (e[t][0] + e[t][1]) + (e[t][2] + e[t][3]);
-            es_all += es;
-            fr[t] += set ? -es : es;
+            qs_all += (q[t][0] + q[t][1]) + (q[t][2] + q[t][3]);
+            if (GRAD) {
+                const float es = (e[t][0] + e[t][1]) + (e[t][2] + e[t][3]);
+                fr[t] += set ? -es : es;
+            }
         }
-        if (set) f1 = fmaf(wsym, es_all, f1);
-        else f0 += es_all;
+        if (set) f1 = fmaf(wsym, qs_all, f1);
+        else f0 += qs_all;
         if (((tile - tb) & 7) == 7) {
             sum0 += (double)f0; sum1 += (double)f1;
             f0 = f1 = 0.f;

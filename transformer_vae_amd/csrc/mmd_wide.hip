@@ -6,13 +6,14 @@
 //   for each strip of R local rows (R sized so that the strip of the kernel matrix stays ~256 MiB):
 //     S  = Zs Z^T | Zs Y^T            two GEMMs into one R x 2N strip
 //     E  = expm1(-max((|z_i|^2 + |x_j|^2 - 2 S) / D^2, 0)), prior columns negated, in place;
-//          per-row fp64 sums (zz, zy, signed row sum R_i)        one workgroup per row, fixed order
+//          per-row fp64 sums of Q = E + t (zz, zy) and the signed row sum R_i of E
+//          (the part of the sums linear in t is added in closed form, see em1_split)   one workgroup per row
 //     G  = E[:, :N] Z + E[:, N:] Y    two GEMMs (split-K slabs, deterministic)
 //     dz = grad_scale (-z R + (colsum z - colsum y) + G)
 //   the y-y sum runs the same strips with one GEMM and the sums only.
 // Same math and the same E-form as mmd.hip (the "+1"s cancel exactly); only strips of the N x N matrices
 // ever exist.  bf16 inputs are widened once to fp32 copies (exact).
-#include "tvae_common.h"
+#include "mmd_common.h"
 
 namespace tvae {
 namespace {
@@ -22,7 +23,7 @@ constexpr int64_t STRIP_BYTES = 256ll << 20;
 struct WidePlan {
     int R;                      // rows per strip
     int64_t slab_floats;
-    int64_t off_zf, off_yf, off_zn, off_yn, off_csz, off_csy, off_cscr, off_S, off_G1, off_G2, off_slab;
+    int64_t off_zf, off_yf, off_zn, off_yn, off_csz, off_csy, off_cszl, off_csyl, off_cscr, off_S, off_G1, off_G2, off_slab;
     int64_t off_rsum, off_rzz, off_rzy, off_ryy, bytes;
 };
 
@@ -44,6 +45,8 @@ WidePlan wide_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad) {
     p.off_yn = take(n_total * 4);
     p.off_csz = take(D * 4);
     p.off_csy = take(D * 4);
+    p.off_cszl = take(D * 4);
+    p.off_csyl = take(D * 4);
     p.off_cscr = take(colreduce_scratch_floats(n_total, D) * 4);
     p.off_S = take(R * 2 * n_total * 4);
     p.off_G1 = take(want_grad ? R * D * 4 : 0);
@@ -85,29 +88,35 @@ __global__ __launch_bounds__(256) void wide_e_kernel(float* __restrict__ S, long
     const int i = blockIdx.x, tid = threadIdx.x;
     float* row = S + (long long)i * ld;
     const float rn = rnorm[i];
-    double sa = 0.0, sb = 0.0;
-    for (int j = tid; j < n0; j += 256) {
-        const float t = fmaxf((rn + cn0[j] - 2.f * row[j]) * inv_d2, 0.f);
+    double qa = 0.0, qb = 0.0, es = 0.0;      // sums of Q per set, signed sum of E
+    auto eq = [](float t) -> EQ {
+        if (t < EM1_POLY_MAX) return em1_split(t);
         const float e = expm1f(-t);
-        row[j] = e;
-        sa += (double)e;
+        return EQ{e, e + t};
+    };
+    for (int j = tid; j < n0; j += 256) {
+        const EQ v = eq(fmaxf((rn + cn0[j] - 2.f * row[j]) * inv_d2, 0.f));
+        row[j] = v.e;
+        qa += (double)v.q;
+        es += (double)v.e;
     }
     for (int j = tid; j < n1; j += 256) {
-        const float t = fmaxf((rn + cn1[j] - 2.f * row[n0 + j]) * inv_d2, 0.f);
-        const float e = expm1f(-t);
-        row[n0 + j] = -e;
-        sb += (double)e;
+        const EQ v = eq(fmaxf((rn + cn1[j] - 2.f * row[n0 + j]) * inv_d2, 0.f));
+        row[n0 + j] = -v.e;
+        qb += (double)v.q;
+        es -= (double)v.e;
     }
-    red[0][tid] = sa; red[1][tid] = sb;
+    __shared__ double red3[256];
+    red[0][tid] = qa; red[1][tid] = qb; red3[tid] = es;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red3[tid] += red3[tid + o]; }
         __syncthreads();
     }
     if (tid == 0) {
         if (out_a) out_a[i] = red[0][0];
         if (out_b) out_b[i] = red[1][0];
-        if (out_signed) out_signed[i] = red[0][0] - red[1][0];
+        if (out_signed) out_signed[i] = red3[0];
     }
 }
 
@@ -128,23 +137,43 @@ __global__ __launch_bounds__(256) void wide_dz_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void wide_final_kernel(const double* __restrict__ rzz, const double* __restrict__ rzy,
                                                          const double* __restrict__ ryy, long long rows,
-                                                         double* __restrict__ sums3, float* __restrict__ loss,
+                                                         const float* __restrict__ zn, const float* __restrict__ yn,
+                                                         long long n_total, long long row_offset,
+                                                         const float* __restrict__ csz, const float* __restrict__ csy,
+                                                         const float* __restrict__ cszl, const float* __restrict__ csyl,
+                                                         int D, double* __restrict__ sums3, float* __restrict__ loss,
                                                          double loss_scale) {
-    __shared__ double red[3][256];
+    __shared__ double red[10][256];
     const int tid = threadIdx.x;
-    double a = 0.0, b = 0.0, c = 0.0;
-    for (long long i = tid; i < rows; i += 256) { a += rzz[i]; b += rzy[i]; c += ryy[i]; }
-    red[0][tid] = a; red[1][tid] = b; red[2][tid] = c;
+    double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long i = tid; i < rows; i += 256) { v[0] += rzz[i]; v[1] += rzy[i]; v[2] += ryy[i]; }
+    for (long long i = tid; i < n_total; i += 256) {         // squared norms: all points / this call's rows
+        const double a = (double)zn[i], b = (double)yn[i];
+        v[3] += a; v[4] += b;
+        if (i >= row_offset && i < row_offset + rows) { v[5] += a; v[6] += b; }
+    }
+    for (int c = tid; c < D; c += 256) {                     // <c_z^loc, c_z>, <c_z^loc, c_y>, <c_y^loc, c_y>
+        v[7] += (double)cszl[c] * (double)csz[c];
+        v[8] += (double)cszl[c] * (double)csy[c];
+        v[9] += (double)csyl[c] * (double)csy[c];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) red[k][tid] = v[k];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) {
-            red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) red[k][tid] += red[k][tid + o];
         }
         __syncthreads();
     }
     if (tid == 0) {
-        sums3[0] = red[0][0]; sums3[1] = red[1][0]; sums3[2] = red[2][0];
-        if (loss) *loss = (float)(loss_scale * (red[2][0] + red[0][0] - 2.0 * red[1][0]));
+        const double N = (double)n_total, nl = (double)rows, inv = 1.0 / ((double)D * (double)D);
+        const double szz = red[0][0] - (N * red[5][0] + nl * red[3][0] - 2.0 * red[7][0]) * inv;
+        const double szy = red[1][0] - (N * red[5][0] + nl * red[4][0] - 2.0 * red[8][0]) * inv;
+        const double syy = red[2][0] - (N * red[6][0] + nl * red[4][0] - 2.0 * red[9][0]) * inv;
+        sums3[0] = szz; sums3[1] = szy; sums3[2] = syy;
+        if (loss) *loss = (float)(loss_scale * (syy + szz - 2.0 * szy));
     }
 }
 
@@ -211,10 +240,12 @@ int mmd_wide_launch(const void* z_all, const void* y_all, int64_t n_total, int64
     hipLaunchKernelGGL(wide_rownorm_kernel, dim3(nb), dim3(256), 0, s, zf, zn, (long long)n_total, Di);
     hipLaunchKernelGGL(wide_rownorm_kernel, dim3(nb), dim3(256), 0, s, yf, yn, (long long)n_total, Di);
     TVAE_CHECK_HIP(hipGetLastError());
-    if (want_grad) {
-        TVAE_PROPAGATE(colsum(zf, n_total, D, csz, TVAE_F32, cscr, s));
-        TVAE_PROPAGATE(colsum(yf, n_total, D, csy, TVAE_F32, cscr, s));
-    }
+    float* cszl = reinterpret_cast<float*>(ws + p.off_cszl);
+    float* csyl = reinterpret_cast<float*>(ws + p.off_csyl);
+    TVAE_PROPAGATE(colsum(zf, n_total, D, csz, TVAE_F32, cscr, s));
+    TVAE_PROPAGATE(colsum(yf, n_total, D, csy, TVAE_F32, cscr, s));
+    TVAE_PROPAGATE(colsum(zf + row_offset * D, n_rows, D, cszl, TVAE_F32, cscr, s));
+    TVAE_PROPAGATE(colsum(yf + row_offset * D, n_rows, D, csyl, TVAE_F32, cscr, s));
 
     for (int64_t r0 = 0; r0 < n_rows; r0 += p.R) {
         const int Rc = (int)(n_rows - r0 < p.R ? n_rows - r0 : p.R);
@@ -245,8 +276,8 @@ int mmd_wide_launch(const void* z_all, const void* y_all, int64_t n_total, int64
                            (const float*)nullptr, 0, inv_d2, ryy + r0, (double*)nullptr, (double*)nullptr);
         TVAE_CHECK_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(wide_final_kernel, dim3(1), dim3(256), 0, s, rzz, rzy, ryy, (long long)n_rows, sums3, loss,
-                       loss_scale);
+    hipLaunchKernelGGL(wide_final_kernel, dim3(1), dim3(256), 0, s, rzz, rzy, ryy, (long long)n_rows, zn, yn,
+                       (long long)n_total, (long long)row_offset, csz, csy, cszl, csyl, Di, sums3, loss, loss_scale);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }
