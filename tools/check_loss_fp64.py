@@ -32,3 +32,18 @@ for name, got, want in (("zz", sums[0], szz), ("zy", sums[1], szy), ("yy", sums[
 zi = z.clone().requires_grad_(True)
 loss = F.mmd_reg_loss(zi, y, batch_size=1, n_latents=1)
 print("N %d D %d  kernel %.9e  fp64 %.9e  rel err %.2e" % (N, D, float(loss.detach()), float(ref), abs(float(loss.detach()) - float(ref)) / abs(float(ref))))
+
+if len(sys.argv) > 3:      # gradient check (closed form in fp64, chunked)
+    z64, y64 = z.double(), y.double()
+    nz, ny = (z64 * z64).sum(1), (y64 * y64).sum(1)
+    shift = z64.sum(0) - y64.sum(0)
+    gref = torch.empty_like(z64)
+    for r0 in range(0, N, 2048):
+        zr = z64[r0:r0 + 2048]
+        ezz = torch.expm1(-((nz[r0:r0 + 2048, None] + nz[None, :] - 2 * zr @ z64.T) / float(D * D)).clamp_min(0))
+        ezy = torch.expm1(-((nz[r0:r0 + 2048, None] + ny[None, :] - 2 * zr @ y64.T) / float(D * D)).clamp_min(0))
+        rs = ezz.sum(1) - ezy.sum(1)
+        gref[r0:r0 + 2048] = (-(zr * rs[:, None]) + shift[None, :] + ezz @ z64 - ezy @ y64) * (4.0 / (float(N) ** 2 * D * D))
+    loss.backward()
+    err = (zi.grad.double() - gref).abs().max() / gref.abs().max()
+    print("  gradient max err / max |g| = %.2e   (max |g| %.3e)" % (float(err), float(gref.abs().max())))
