@@ -7,11 +7,20 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 out = []
-for f in glob.glob(f"{src}/trace/*/*_kernel_stats.csv"):
+import os
+
+
+def newest(pattern):
+    """gpurun_out keeps files of earlier runs: take the most recent match only."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(f"{src}/trace/*/*_kernel_stats.csv"):
     out.append("# rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
     out += [l.rstrip()[:220] for l in open(f).readlines()[:10]]
 for d in ["pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"]:
-    for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
+    for f in newest(f"{src}/{d}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         calls = collections.Counter()
         for r in csv.DictReader(open(f)):
