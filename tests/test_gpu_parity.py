@@ -583,3 +583,16 @@ def test_mmd_loss_at_scale_against_fp64(N, D, dtype):
     ref = _mmd_fp64_on_gpu(z, y)
     loss = F.mmd_reg_loss(z.clone().requires_grad_(True), y, batch_size=1, n_latents=1)
     assert abs(float(loss.detach()) - ref) <= 1e-6 * abs(ref), (float(loss.detach()), ref)
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
+def test_full_size_projections_against_fp64(name):
+    """BASELINE cfg3 / cfg4 at FULL size: encode, decode + LayerNorm forward and every gradient against torch fp64
+    on the GPU (K = 245 760 rows in the weight-gradient products at cfg4; split-K slabs summed in a fixed order)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_proj_fp64", os.path.join(os.path.dirname(__file__), "..", "tools",
+                                                                               "check_proj_fp64.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(name)
+    assert all(v <= F32_TOL for v in res.values()), res
