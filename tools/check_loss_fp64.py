@@ -14,7 +14,7 @@ z = torch.tanh(torch.randn((N, D), generator=g, device=dev))
 y = torch.randn((N, D), generator=g, device=dev)
 
 
-def esum(a, b, chunk=4096):
+def esum(a, b, chunk=2048):
     a64, b64 = a.double(), b.double()
     na, nb = (a64 * a64).sum(1), (b64 * b64).sum(1)
     tot = torch.zeros((), dtype=torch.float64, device=dev)
