@@ -596,3 +596,18 @@ def test_full_size_projections_against_fp64(name):
     spec.loader.exec_module(mod)
     res = mod.run(name)
     assert all(v <= F32_TOL for v in res.values()), res
+
+
+@pytest.mark.parametrize("N,D,dtype", [(8200, 77, torch.float32), (2100, 300, torch.bfloat16), (1500, 768, torch.float32),
+                                       (300, 1100, torch.float32), (350, 77, torch.float32)])
+def test_mmd_forward_only_equals_training_mode(N, D, dtype):
+    """Without a gradient request both problems run in one sum-only launch: same loss (bitwise for the tile kernels'
+    shared y-y launch is not required; 1e-7 is) as the training-mode call, for every kernel family."""
+    from transformer_vae_amd import functional as F
+    gen = torch.Generator(device=dev()).manual_seed(N * 7 + D)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev())).to(dtype)
+    y = torch.randn((N, D), generator=gen, device=dev()).to(dtype)
+    with torch.no_grad():
+        a = F.mmd_reg_loss(z, y, batch_size=2, n_latents=3)
+    b = F.mmd_reg_loss(z.clone().requires_grad_(True), y, batch_size=2, n_latents=3)
+    assert abs(float(a) - float(b.detach())) <= 1e-6 * abs(float(b.detach())), (float(a), float(b.detach()))
