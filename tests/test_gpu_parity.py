@@ -611,3 +611,40 @@ def test_mmd_forward_only_equals_training_mode(N, D, dtype):
         a = F.mmd_reg_loss(z, y, batch_size=2, n_latents=3)
     b = F.mmd_reg_loss(z.clone().requires_grad_(True), y, batch_size=2, n_latents=3)
     assert abs(float(a) - float(b.detach())) <= 1e-6 * abs(float(b.detach())), (float(a), float(b.detach()))
+
+
+def test_strided_views_as_inputs():
+    """Hidden states that are strided views (every second batch row / sequence position of a larger buffer, a
+    transposed feature layout), a non-contiguous injected prior, and a non-contiguous cotangent: same results as
+    their contiguous copies (the kernels take batch / sequence strides; anything else is compacted on the GPU)."""
+    B, S, d, n, L = 6, 9, 32, 3, 11
+    h, params, prior, g0 = orc.synth_inputs(B, S, d, n, L, 10, "")
+    vae = build_vae(d, L, n, "", params)
+    prior_t, g0_t = torch.from_numpy(prior).to(dev()), torch.from_numpy(g0).to(dev())
+
+    def run(h_in, prior_in, cot):
+        for p in vae.parameters():
+            p.grad = None
+        out = vae(input_encoding=h_in, true_samples=prior_in)
+        (out.reg_loss * 0.5 + (out.reconstructed_encoding * cot).sum()).backward()
+        return (out.latent.detach().clone(), float(out.reg_loss.detach()), vae.encoder.token_to_latent.weight.grad.clone())
+
+    base_h = torch.from_numpy(h).to(dev()).requires_grad_(True)
+    lat0, reg0, gw0 = run(base_h, prior_t, g0_t)
+    gh0 = base_h.grad.clone()
+
+    big = torch.zeros((2 * B, 2 * S, d), device=dev())
+    big[::2, ::2] = torch.from_numpy(h).to(dev())
+    big.requires_grad_(True)
+    view = big[::2, ::2]                                   # batch and sequence strides doubled
+    prior_nc = torch.zeros((B * n, 2 * L), device=dev())
+    prior_nc[:, ::2] = prior_t
+    cot_nc = torch.zeros((B, n, 2 * d), device=dev())
+    cot_nc[..., ::2] = g0_t
+    lat1, reg1, gw1 = run(view, prior_nc[:, ::2], cot_nc[..., ::2])
+    assert torch.equal(lat1, lat0) and reg1 == reg0 and torch.equal(gw1, gw0)
+    assert torch.equal(big.grad[::2, ::2], gh0) and float(big.grad[1::2].abs().max()) == 0.0
+
+    ht = torch.from_numpy(h).to(dev()).transpose(1, 2).contiguous().transpose(1, 2).requires_grad_(True)   # feature stride != 1
+    lat2, reg2, gw2 = run(ht, prior_t, g0_t)
+    assert torch.equal(lat2, lat0) and reg2 == reg0 and torch.equal(gw2, gw0)
