@@ -648,3 +648,40 @@ def test_strided_views_as_inputs():
     ht = torch.from_numpy(h).to(dev()).transpose(1, 2).contiguous().transpose(1, 2).requires_grad_(True)   # feature stride != 1
     lat2, reg2, gw2 = run(ht, prior_t, g0_t)
     assert torch.equal(lat2, lat0) and reg2 == reg0 and torch.equal(gw2, gw0)
+
+
+def test_two_host_threads_on_their_own_streams():
+    """nn.DataParallel drives replicas from several host threads: the library keeps no shared mutable state, so two
+    threads on their own streams reproduce the sequential results bit for bit."""
+    import threading
+    B, S, d, n, L = 8, 60, 512, 5, 77
+    h, params, prior, g0 = orc.synth_inputs(B, S, d, n, L, 1, "")
+    prior_t, g0_t = torch.from_numpy(prior).to(dev()), torch.from_numpy(g0).to(dev())
+
+    def work(seed, out, stream=None):
+        vae = build_vae(d, L, n, "", params)
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        x = (torch.from_numpy(h) + 0.1 * torch.randn(h.shape, generator=gen)).to(dev()).requires_grad_(True)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            for _ in range(5):
+                x.grad = None
+                o = vae(input_encoding=x, true_samples=prior_t)
+                (o.reg_loss * 0.5 + (o.reconstructed_encoding * g0_t).sum()).backward()
+            if stream is not None:
+                stream.synchronize()
+        out[seed] = (float(o.reg_loss.detach()), x.grad.clone(), vae.decoder.norm.weight.grad.clone())
+
+    torch.cuda.synchronize()
+    seq, par = {}, {}
+    work(1, seq)
+    work(2, seq)
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=work, args=(s, par, torch.cuda.Stream(dev()))) for s in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for s in (1, 2):
+        assert par[s][0] == seq[s][0] and torch.equal(par[s][1], seq[s][1]) and torch.equal(par[s][2], seq[s][2])
