@@ -685,3 +685,29 @@ def test_two_host_threads_on_their_own_streams():
     torch.cuda.synchronize()
     for s in (1, 2):
         assert par[s][0] == seq[s][0] and torch.equal(par[s][1], seq[s][1]) and torch.equal(par[s][2], seq[s][2])
+
+
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
+def test_under_autocast_like_the_trainer(amp_dtype):
+    """HF Trainer --fp16 / --bf16 wraps the step in autocast (trainer.py:259-263): fp32 parameters and inputs.
+    bf16 autocast computes on bf16 storage (1e-2 bar); fp16 autocast keeps this path in fp32 (>= the reference's
+    precision, 1e-5 bar).  Parameter gradients come back in the parameters' dtype."""
+    g, (B, S, d, n, L), h, params, prior, g0 = None, (8, 60, 512, 5, 77), *orc.synth_inputs(8, 60, 512, 5, 77, 1, "")
+    vae = build_vae(d, L, n, "", params)
+    x = torch.from_numpy(h).to(dev()).requires_grad_(True)
+    prior_t, g0_t = torch.from_numpy(prior).to(dev()), torch.from_numpy(g0).to(dev())
+    with torch.autocast("cuda", dtype=amp_dtype):
+        out = vae(input_encoding=x, true_samples=prior_t)
+        loss = out.reg_loss.float() * 0.5 + (out.reconstructed_encoding.float() * g0_t).sum()
+    loss.backward()
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    fwd = orc.bottleneck_forward(h.astype(np.float64), p64, n, prior.astype(np.float64), 1e-9)
+    bwd = orc.bottleneck_backward(h.astype(np.float64), p64, n, fwd, g0.astype(np.float64), 0.5, prior.astype(np.float64))
+    tol = BF16_TOL if amp_dtype == torch.bfloat16 else F32_TOL
+    assert out.reg_loss.dtype == torch.float32
+    assert abs(float(out.reg_loss.detach()) - fwd["reg_loss"]) <= tol * abs(fwd["reg_loss"])
+    assert relerr(out.latent.detach().float().cpu().numpy(), fwd["latent"]) <= tol
+    assert relerr(out.reconstructed_encoding.detach().float().cpu().numpy(), fwd["recon"]) <= tol
+    gw = vae.encoder.token_to_latent.weight.grad
+    assert gw.dtype == torch.float32 and x.grad.dtype == torch.float32
+    assert relerr(gw.cpu().numpy(), bwd["We"]) <= tol and relerr(x.grad.cpu().numpy(), bwd["h"]) <= tol
