@@ -711,3 +711,19 @@ def test_under_autocast_like_the_trainer(amp_dtype):
     gw = vae.encoder.token_to_latent.weight.grad
     assert gw.dtype == torch.float32 and x.grad.dtype == torch.float32
     assert relerr(gw.cpu().numpy(), bwd["We"]) <= tol and relerr(x.grad.cpu().numpy(), bwd["h"]) <= tol
+
+
+@pytest.mark.parametrize("N,D", [(1, 7), (2, 77), (3, 768), (1, 1100)])
+def test_mmd_tiny_sample_counts(N, D):
+    """One to three latent codes (batch 1, a single latent token): every kernel family against the oracle."""
+    from transformer_vae_amd import functional as F
+    rs = np.random.RandomState(N * 100 + D)
+    z = np.tanh(rs.standard_normal((N, D))).astype(np.float32)
+    y = rs.standard_normal((N, D)).astype(np.float32)
+    zt = torch.from_numpy(z).to(dev()).requires_grad_(True)
+    reg = F.mmd_reg_loss(zt, torch.from_numpy(y).to(dev()), batch_size=1, n_latents=N)
+    reg.backward()
+    ref = orc.mmd_gram(y.astype(np.float64), z.astype(np.float64)) * N
+    gref = orc.mmd_grad_latent_rows(z.astype(np.float64), z.astype(np.float64), y.astype(np.float64)) * N
+    assert abs(float(reg.detach()) - ref) <= F32_TOL * abs(ref), (float(reg.detach()), ref)
+    assert relerr(zt.grad.cpu().numpy(), gref) <= F32_TOL
