@@ -727,3 +727,29 @@ def test_mmd_tiny_sample_counts(N, D):
     gref = orc.mmd_grad_latent_rows(z.astype(np.float64), z.astype(np.float64), y.astype(np.float64)) * N
     assert abs(float(reg.detach()) - ref) <= F32_TOL * abs(ref), (float(reg.detach()), ref)
     assert relerr(zt.grad.cpu().numpy(), gref) <= F32_TOL
+
+
+@pytest.mark.parametrize("N,D,scale,dtype", [(300, 5, 8.0, torch.float32), (700, 77, 12.0, torch.float32),
+                                             (9000, 40, 6.0, torch.float32), (600, 768, 30.0, torch.float32),
+                                             (600, 768, 30.0, torch.bfloat16), (200, 1100, 40.0, torch.float32),
+                                             (256, 64, 0.0, torch.float32)])
+def test_mmd_far_apart_and_coincident_points(N, D, scale, dtype):
+    """Large distances (t beyond the polynomial range: the library-exp branch of every kernel family, E -> -1) and,
+    with scale 0, priors that coincide with the latents (t = 0 exactly, clamped)."""
+    from transformer_vae_amd import functional as F
+    rs = np.random.RandomState(N + D)
+    z = np.tanh(rs.standard_normal((N, D))).astype(np.float32)
+    y = (rs.standard_normal((N, D)) * scale).astype(np.float32) if scale else z.copy()
+    zt = torch.from_numpy(z).to(dev()).to(dtype).requires_grad_(True)
+    yt = torch.from_numpy(y).to(dev()).to(dtype)
+    reg = F.mmd_reg_loss(zt, yt, batch_size=1, n_latents=1)
+    reg.backward()
+    z64, y64 = zt.detach().double().cpu().numpy(), yt.double().cpu().numpy()
+    ref = orc.mmd_gram(y64, z64)
+    gref = orc.mmd_grad_latent_rows(z64, z64, y64)
+    if scale:
+        assert abs(float(reg.detach()) - ref) <= F32_TOL * abs(ref), (float(reg.detach()), ref)
+        assert relerr(zt.grad.float().cpu().numpy(), gref) <= (F32_TOL if dtype == torch.float32 else BF16_TOL)
+    else:
+        assert abs(float(reg.detach())) <= 1e-9 and abs(ref) <= 1e-12       # MMD of a sample with itself is 0
+        assert float(zt.grad.abs().max()) <= 1e-6 * max(np.abs(gref).max(), 1e-12) + 1e-12
