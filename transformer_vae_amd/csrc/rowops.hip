@@ -60,6 +60,119 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const T* __restrict__ 
     }
 }
 
+// ---- register-resident variants: one wave per row, the row is read ONCE with 16-byte (fp32) / 8-byte (bf16)
+//      loads and stays in registers for the statistics and the output pass.  d % 4 == 0, d <= 256 * LN_MAXG,
+//      16-byte aligned rows; anything else takes the scalar kernels above.  The summation order differs from
+//      the scalar kernels only in how a lane strides the row (groups of four), not in the wave reduction.
+constexpr int LN_MAXG = 8;      // 4-element groups per lane -> d <= 2048
+
+__device__ __forceinline__ void store4_vec(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4_vec(bf16* p, const float v[4]) {
+    uint2 u;
+    u.x = (uint32_t)__bfloat16_as_ushort(__float2bfloat16(v[0])) | ((uint32_t)__bfloat16_as_ushort(__float2bfloat16(v[1])) << 16);
+    u.y = (uint32_t)__bfloat16_as_ushort(__float2bfloat16(v[2])) | ((uint32_t)__bfloat16_as_ushort(__float2bfloat16(v[3])) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ r, const T* __restrict__ gamma,
+                                                         const T* __restrict__ beta, float eps, T* __restrict__ out,
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                                         long long rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* x = r + row * d;
+    const int ng = d >> 2;
+    float v[LN_MAXG][4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXG; ++k) {
+        const int gidx = lane + 64 * k;
+        if (gidx < ng) {
+            load4_vec(x + 4 * gidx, v[k]);
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+    }
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXG; ++k)
+        if (lane + 64 * k < ng) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = v[k][e] - mu; q = fmaf(t, t, q); }
+        }
+    const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+    T* o = out + row * d;
+#pragma unroll
+    for (int k = 0; k < LN_MAXG; ++k) {
+        const int gidx = lane + 64 * k;
+        if (gidx < ng) {
+            float gm[4], bt[4], w[4];
+            load4_vec(gamma + 4 * gidx, gm);
+            load4_vec(beta + 4 * gidx, bt);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (v[k][e] - mu) * rs * gm[e] + bt[e];
+            store4_vec(o + 4 * gidx, w);
+        }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_rows_vec_kernel(const T* __restrict__ dout, const T* __restrict__ r,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const T* __restrict__ gamma, T* __restrict__ dr,
+                                                              long long rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* g = dout + row * d;
+    const T* x = r + row * d;
+    const float mu = mean[row], rs = rstd[row];
+    const int ng = d >> 2;
+    float dxh[LN_MAXG][4], xh[LN_MAXG][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXG; ++k) {
+        const int gidx = lane + 64 * k;
+        if (gidx < ng) {
+            float gv[4], gm[4];
+            load4_vec(g + 4 * gidx, gv);
+            load4_vec(gamma + 4 * gidx, gm);
+            load4_vec(x + 4 * gidx, xh[k]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dxh[k][e] = gv[e] * gm[e];
+                xh[k][e] = (xh[k][e] - mu) * rs;
+                s1 += dxh[k][e];
+                s2 = fmaf(dxh[k][e], xh[k][e], s2);
+            }
+        }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+    T* o = dr + row * d;
+#pragma unroll
+    for (int k = 0; k < LN_MAXG; ++k) {
+        const int gidx = lane + 64 * k;
+        if (gidx < ng) {
+            float w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = rs * (dxh[k][e] - s1 - xh[k][e] * s2);
+            store4_vec(o + 4 * gidx, w);
+        }
+    }
+}
+
+inline bool ln_vec_ok(int64_t d, int dtype, const void* a, const void* b, const void* c, const void* e) {
+    const uintptr_t align = dtype == TVAE_F32 ? 16 : 8;
+    auto ok = [&](const void* p) { return p == nullptr || reinterpret_cast<uintptr_t>(p) % align == 0; };
+    return d % 4 == 0 && d <= 256 * LN_MAXG && ok(a) && ok(b) && ok(c) && ok(e);
+}
+
 // ---- column reductions: partial[chunk][c] over COL_CHUNK_ROWS rows, then a fixed-order sum ----
 // MODE 0: sum_r x[r][c];  MODE 1: (sum_r dout*xhat, sum_r dout) for LayerNorm gamma/beta.
 template <typename T, int MODE>
@@ -74,6 +187,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ 
     const long long rend = min(rows, rbeg + (long long)COL_CHUNK_ROWS);
     float a0 = 0.f, a1 = 0.f;
     if (c < cols) {
+#pragma unroll 8      // eight rows in flight per thread: the loop is a chain of dependent-latency loads otherwise
         for (long long row = rbeg + ry; row < rend; row += 4) {
             const float v = to_f32(x[row * cols + c]);
             if (MODE == 0) {
@@ -151,6 +265,16 @@ inline int col_chunks(int64_t rows) { return (int)((rows + COL_CHUNK_ROWS - 1) /
 int layernorm_fwd(const void* r, const void* gamma, const void* beta, float eps, void* out, float* mean, float* rstd,
                   int64_t rows, int64_t d, int dtype, hipStream_t s) {
     if (rows == 0) return TVAE_OK;
+    if (ln_vec_ok(d, dtype, r, gamma, beta, out)) {
+        if (dtype == TVAE_F32)
+            hipLaunchKernelGGL(ln_fwd_vec_kernel<float>, dim3(row_blocks(rows)), dim3(256), 0, s, (const float*)r,
+                               (const float*)gamma, (const float*)beta, eps, (float*)out, mean, rstd, (long long)rows, (int)d);
+        else
+            hipLaunchKernelGGL(ln_fwd_vec_kernel<bf16>, dim3(row_blocks(rows)), dim3(256), 0, s, (const bf16*)r,
+                               (const bf16*)gamma, (const bf16*)beta, eps, (bf16*)out, mean, rstd, (long long)rows, (int)d);
+        TVAE_CHECK_HIP(hipGetLastError());
+        return TVAE_OK;
+    }
     if (dtype == TVAE_F32)
         hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(row_blocks(rows)), dim3(256), 0, s, (const float*)r,
                            (const float*)gamma, (const float*)beta, eps, (float*)out, mean, rstd, (long long)rows, (int)d);
@@ -164,6 +288,16 @@ int layernorm_fwd(const void* r, const void* gamma, const void* beta, float eps,
 int layernorm_bwd_rows(const void* dout, const void* r, const float* mean, const float* rstd, const void* gamma,
                        void* dr, int64_t rows, int64_t d, int dtype, hipStream_t s) {
     if (rows == 0) return TVAE_OK;
+    if (ln_vec_ok(d, dtype, dout, r, gamma, dr)) {
+        if (dtype == TVAE_F32)
+            hipLaunchKernelGGL(ln_bwd_rows_vec_kernel<float>, dim3(row_blocks(rows)), dim3(256), 0, s, (const float*)dout,
+                               (const float*)r, mean, rstd, (const float*)gamma, (float*)dr, (long long)rows, (int)d);
+        else
+            hipLaunchKernelGGL(ln_bwd_rows_vec_kernel<bf16>, dim3(row_blocks(rows)), dim3(256), 0, s, (const bf16*)dout,
+                               (const bf16*)r, mean, rstd, (const bf16*)gamma, (bf16*)dr, (long long)rows, (int)d);
+        TVAE_CHECK_HIP(hipGetLastError());
+        return TVAE_OK;
+    }
     if (dtype == TVAE_F32)
         hipLaunchKernelGGL(ln_bwd_rows_kernel<float>, dim3(row_blocks(rows)), dim3(256), 0, s, (const float*)dout,
                            (const float*)r, mean, rstd, (const float*)gamma, (float*)dr, (long long)rows, (int)d);
