@@ -8,6 +8,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+from transformer_vae_amd import _lib  # noqa: E402
+
+if os.environ.get("TVAE_LIB_OVERRIDE"):          # kernel experiments: load a variant build instead
+    _lib.LIB_PATH = os.path.abspath(os.environ["TVAE_LIB_OVERRIDE"])
 
 name = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
