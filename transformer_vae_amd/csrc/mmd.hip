@@ -70,9 +70,11 @@ template <int NB, int WAVES, bool GRAD>
 __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
     using L = TileLds<NB, WAVES>;
     constexpr int SW = L::SW, DPAD = WAVES * SW;
+    constexpr bool RS = (WAVES == 8);      // reduce-scatter exchange: one S' element per lane of the workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int my_t = wave & 1, my_r = (wave >> 1) & 3;     // RS: the row group / accumulator register this wave finishes
     const int i16 = lane & 15, g = lane >> 4;
     const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     f32x4* xch = reinterpret_cast<f32x4*>(smem + L::XCH_OFF);
@@ -115,6 +117,8 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         for (int m = 0; m < NB; ++m) asm volatile("" : "+v"(zreg[t][m]));
         asm volatile("" : "+v"(rn[t]));
     }
+    const float rn_my = my_t ? rn[1] : rn[0];
+    const bool valid_my = my_t ? valid_i[1] : valid_i[0];
 
     f32x4 acc[GRAD ? NB : 1][2];
     if (GRAD) {
@@ -230,78 +234,136 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 
         asm volatile("" ::"v"(s0), "v"(s1));
         PHASE_MARK(0);
-        // 3. exchange the slice partials through LDS (raw s_barrier: no vmcnt drain); double buffered,
-        //    so one barrier per tile
-        //    (WAVES == 1: narrow latents — one wave holds the whole feature dimension, nothing to exchange)
-        if (WAVES > 1) {
-            f32x4* xb = xch + buf * (L::XCH_ONE / 4);
-            xb[(wave * 2 + 0) * 64 + lane] = s0;
-            xb[(wave * 2 + 1) * 64 + lane] = s1;
+        f32x4 e0, e1;
+        if constexpr (RS) {
+            // 3'. REDUCE-SCATTER exchange (8 waves): the 16 x 32 tile of S' has one element per lane of the workgroup.
+            //     Wave w finishes register r = w >> 1 of row group t = w & 1 only -- eight conflict-free scalar
+            //     reads instead of sixteen 16-byte ones, and one expm1 per lane instead of eight replicated in
+            //     every wave (VALU work issues through the same port as the MFMAs of the SIMD's other wave).
+            //     Partials and E are stored component-major ([.][t][r][lane]).  Gradient instantiation: a second
+            //     barrier publishes E, which also protects the single partial buffer; sum-only: buffers alternate.
+            float* xp = smem + L::XCH_OFF + (GRAD ? 0 : buf * L::XCH_ONE);
+            float* eb = smem + L::XCH_OFF + L::XCH_ONE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xp[((wave * 2 + 0) * 4 + r) * 64 + lane] = s0[r];
+                xp[((wave * 2 + 1) * 4 + r) * 64 + lane] = s1[r];
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            s0 = xb[(0 * 2 + 0) * 64 + lane];
-            s1 = xb[(0 * 2 + 1) * 64 + lane];
+            const float* mine = xp + (my_t * 4 + my_r) * 64 + lane;
+            float sv = mine[0];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) {      // fixed order: identical in every wave, deterministic
-                s0 += xb[(w * 2 + 0) * 64 + lane];
-                s1 += xb[(w * 2 + 1) * 64 + lane];
-            }
-        }
-
-        PHASE_MARK(1);
-        // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
-        const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g);
-        f32x4 t0, t1, e0, e1, q0, q1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            t0[r] = fmaxf((cn[r] + rn[0] - 2.f * s0[r]) * a.inv_d2, 0.f);
-            t1[r] = fmaxf((cn[r] + rn[1] - 2.f * s1[r]) * a.inv_d2, 0.f);
-        }
-        const float tmax = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])),
-                                 fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
-        if (!__any(tmax >= EM1_TINY)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                { const EQ v_ = em1_split_tiny(t0[r]); e0[r] = v_.e; q0[r] = v_.q; }
-                { const EQ v_ = em1_split_tiny(t1[r]); e1[r] = v_.e; q1[r] = v_.q; }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                { const EQ v_ = em1_split(t0[r]); e0[r] = v_.e; q0[r] = v_.q; }
-                { const EQ v_ = em1_split(t1[r]); e1[r] = v_.e; q1[r] = v_.q; }
-            }
-            if (__any(tmax >= EM1_POLY_MAX)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (t0[r] >= EM1_POLY_MAX) { e0[r] = expm1f(-t0[r]); q0[r] = e0[r] + t0[r]; }
-                    if (t1[r] >= EM1_POLY_MAX) { e1[r] = expm1f(-t1[r]); q1[r] = e1[r] + t1[r]; }
+            for (int w = 1; w < WAVES; ++w) sv += mine[w * 512];      // fixed order: deterministic
+            PHASE_MARK(1);
+            const float cnv = smem[L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g + my_r];
+            const float tv = fmaxf((cnv + rn_my - 2.f * sv) * a.inv_d2, 0.f);
+            EQ v_;
+            if (!__any(tv >= EM1_TINY)) {
+                v_ = em1_split_tiny(tv);
+            } else {
+                v_ = em1_split(tv);
+                if (__any(tv >= EM1_POLY_MAX)) {
+                    if (tv >= EM1_POLY_MAX) { v_.e = expm1f(-tv); v_.q = v_.e + tv; }
                 }
             }
-        }
-        if (any_invalid) {
-            if (!valid_i[0]) { e0 = f32x4{0.f, 0.f, 0.f, 0.f}; q0 = e0; }
-            if (!valid_i[1]) { e1 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = e1; }
-        }
-        if (p0 + TILE_P > a.n_cols) {
+            if (any_invalid && !valid_my) { v_.e = 0.f; v_.q = 0.f; }
+            if (p0 + TILE_P > a.n_cols && p0 + 4 * g + my_r >= a.n_cols) { v_.e = 0.f; v_.q = 0.f; }
+            if (set) f1 = fmaf(wsym, v_.q, f1);
+            else f0 += v_.q;
+            const float es = __uint_as_float(__float_as_uint(v_.e) ^ (set ? 0x80000000u : 0u));   // s_p E
+            if (GRAD) fr0 += es;
+            if (((tile - tb) & 7) == 7) {
+                sum0 += (double)f0; sum1 += (double)f1; rowsum0 += (double)fr0;
+                f0 = f1 = fr0 = 0.f;
+            }
+            if (GRAD) {
+                eb[(my_t * 4 + my_r) * 64 + lane] = es;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (p0 + 4 * g + r >= a.n_cols) { e0[r] = 0.f; e1[r] = 0.f; q0[r] = 0.f; q1[r] = 0.f; }
-        }
-        // sums carry Q (the linear part is added in closed form by the finalize kernel); row sums carry E
-        const float qs = ((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
-        if (set) f1 = fmaf(wsym, qs, f1);
-        else f0 += qs;
-        if (GRAD) {
-            const float es0 = (e0[0] + e0[1]) + (e0[2] + e0[3]);
-            const float es1 = (e1[0] + e1[1]) + (e1[2] + e1[3]);
-            fr0 += set ? -es0 : es0;
-            fr1 += set ? -es1 : es1;
-        }
-        if (((tile - tb) & 7) == 7) {
-            sum0 += (double)f0; sum1 += (double)f1; rowsum0 += (double)fr0; rowsum1 += (double)fr1;
-            f0 = f1 = fr0 = fr1 = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    e0[r] = eb[(0 * 4 + r) * 64 + lane];
+                    e1[r] = eb[(1 * 4 + r) * 64 + lane];
+                }
+            }
+        } else {
+            // 3. exchange the slice partials through LDS (raw s_barrier: no vmcnt drain); double buffered,
+            //    so one barrier per tile
+            //    (WAVES == 1: narrow latents — one wave holds the whole feature dimension, nothing to exchange)
+            if (WAVES > 1) {
+                f32x4* xb = xch + buf * (L::XCH_ONE / 4);
+                xb[(wave * 2 + 0) * 64 + lane] = s0;
+                xb[(wave * 2 + 1) * 64 + lane] = s1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                s0 = xb[(0 * 2 + 0) * 64 + lane];
+                s1 = xb[(0 * 2 + 1) * 64 + lane];
+    #pragma unroll
+                for (int w = 1; w < WAVES; ++w) {      // fixed order: identical in every wave, deterministic
+                    s0 += xb[(w * 2 + 0) * 64 + lane];
+                    s1 += xb[(w * 2 + 1) * 64 + lane];
+                }
+            }
+
+            PHASE_MARK(1);
+            // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
+            const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g);
+            f32x4 t0, t1, q0, q1;
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                t0[r] = fmaxf((cn[r] + rn[0] - 2.f * s0[r]) * a.inv_d2, 0.f);
+                t1[r] = fmaxf((cn[r] + rn[1] - 2.f * s1[r]) * a.inv_d2, 0.f);
+            }
+            const float tmax = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])),
+                                     fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
+            if (!__any(tmax >= EM1_TINY)) {
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    { const EQ v_ = em1_split_tiny(t0[r]); e0[r] = v_.e; q0[r] = v_.q; }
+                    { const EQ v_ = em1_split_tiny(t1[r]); e1[r] = v_.e; q1[r] = v_.q; }
+                }
+            } else {
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    { const EQ v_ = em1_split(t0[r]); e0[r] = v_.e; q0[r] = v_.q; }
+                    { const EQ v_ = em1_split(t1[r]); e1[r] = v_.e; q1[r] = v_.q; }
+                }
+                if (__any(tmax >= EM1_POLY_MAX)) {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (t0[r] >= EM1_POLY_MAX) { e0[r] = expm1f(-t0[r]); q0[r] = e0[r] + t0[r]; }
+                        if (t1[r] >= EM1_POLY_MAX) { e1[r] = expm1f(-t1[r]); q1[r] = e1[r] + t1[r]; }
+                    }
+                }
+            }
+            if (any_invalid) {
+                if (!valid_i[0]) { e0 = f32x4{0.f, 0.f, 0.f, 0.f}; q0 = e0; }
+                if (!valid_i[1]) { e1 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = e1; }
+            }
+            if (p0 + TILE_P > a.n_cols) {
+    #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (p0 + 4 * g + r >= a.n_cols) { e0[r] = 0.f; e1[r] = 0.f; q0[r] = 0.f; q1[r] = 0.f; }
+            }
+            // sums carry Q (the linear part is added in closed form by the finalize kernel); row sums carry E
+            const float qs = ((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]));
+            if (set) f1 = fmaf(wsym, qs, f1);
+            else f0 += qs;
+            if (GRAD) {
+                const float es0 = (e0[0] + e0[1]) + (e0[2] + e0[3]);
+                const float es1 = (e1[0] + e1[1]) + (e1[2] + e1[3]);
+                fr0 += set ? -es0 : es0;
+                fr1 += set ? -es1 : es1;
+            }
+            if (((tile - tb) & 7) == 7) {
+                sum0 += (double)f0; sum1 += (double)f1; rowsum0 += (double)fr0; rowsum1 += (double)fr1;
+                f0 = f1 = fr0 = fr1 = 0.f;
+            }
+
         }
 
         // 5. gradient accumulation: acc^T[d][i] += sum_p X[p][d] * (s_p E'[p][i]); block db of the tile is
@@ -309,11 +371,13 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         asm volatile("" ::"v"(e0), "v"(e1));
         PHASE_MARK(2);
         if (GRAD) {
-            const unsigned flip = set ? 0x80000000u : 0u;      // prior columns enter with s_p = -1
+            if constexpr (!RS) {      // (the reduce-scatter path published s_p E already)
+                const unsigned flip = set ? 0x80000000u : 0u;      // prior columns enter with s_p = -1
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e0[r] = __uint_as_float(__float_as_uint(e0[r]) ^ flip);
-                e1[r] = __uint_as_float(__float_as_uint(e1[r]) ^ flip);
+                for (int r = 0; r < 4; ++r) {
+                    e0[r] = __uint_as_float(__float_as_uint(e0[r]) ^ flip);
+                    e1[r] = __uint_as_float(__float_as_uint(e1[r]) ^ flip);
+                }
             }
             float ga[4];
 #pragma unroll
@@ -345,15 +409,35 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
     sum0 += (double)f0; sum1 += (double)f1; rowsum0 += (double)fr0; rowsum1 += (double)fr1;
 
     // ---- per-workgroup results (every wave holds identical sums; wave 0 writes) ----
-    const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
+    double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
+    double r0v = rowsum0, r1v = rowsum1;
+    if (GRAD) {
+        r0v += __shfl_xor(r0v, 16, 64); r0v += __shfl_xor(r0v, 32, 64);
+        r1v += __shfl_xor(r1v, 16, 64); r1v += __shfl_xor(r1v, 32, 64);
+    }
+    if constexpr (RS) {
+        // reduce-scatter: every wave holds the sums of ITS elements -> combine the waves in a fixed order
+        // (the exchange buffers are free once every wave has left the tile loop)
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem + L::XCH_OFF);     // [WAVES][2] sums, then [WAVES][16] row sums
+        if (lane == 0) { red[wave * 2 + 0] = w0; red[wave * 2 + 1] = w1; }
+        if (GRAD && g == 0) red[2 * WAVES + wave * 16 + i16] = r0v;      // row group my_t, row i16
+        __syncthreads();
+        w0 = 0.0; w1 = 0.0;
+        for (int w = 0; w < WAVES; ++w) { w0 += red[w * 2 + 0]; w1 += red[w * 2 + 1]; }
+        if (GRAD) {
+            r0v = 0.0; r1v = 0.0;
+            for (int w = 0; w < WAVES; w += 2) {
+                r0v += red[2 * WAVES + w * 16 + i16];
+                r1v += red[2 * WAVES + (w + 1) * 16 + i16];
+            }
+        }
+    }
     if (tid == 0) {
         a.wg_sums[2 * (long long)bid + 0] = w0;
         a.wg_sums[2 * (long long)bid + 1] = w1;
     }
     if (GRAD) {
-        double r0v = rowsum0, r1v = rowsum1;
-        r0v += __shfl_xor(r0v, 16, 64); r0v += __shfl_xor(r0v, 32, 64);
-        r1v += __shfl_xor(r1v, 16, 64); r1v += __shfl_xor(r1v, 32, 64);
         if (wave == 0 && g == 0) {
             double* rs = a.wg_rowsum + (long long)sp * a.n_rows_pad + i0;
             rs[i16] = r0v;
