@@ -15,10 +15,11 @@
 //   2. Gram: S'[p][i] partial over the slice with v_mfma_f32_16x16x4_f32 — A = point tile
 //      from LDS (ds_read_b128, 4 k-steps per read), B = the 32 rows held in registers for the
 //      whole kernel.  k order inside the dot product is permuted identically for A and B;
-//   3. the 4 partial S' tiles are exchanged through LDS (one barrier per tile, double
-//      buffered) and summed in a fixed order, so every wave holds the full S' in the MFMA
-//      C layout (row p = 4*(lane>>4)+reg, column i = lane&15);
-//   4. E' = expm1(-t) in registers (masked at ragged edges), sums in fp64;
+//   3. the partial S' tiles are REDUCE-SCATTERED through LDS: every wave sums (fixed order) and finishes
+//      only its share of the 16 x 32 tile, so the expm1 work is split over the waves, not replicated;
+//   4. E' = expm1(-t) (masked at ragged edges), sums in fp64; the gradient instantiation publishes E'
+//      through LDS (second barrier) and every wave reads it back in the MFMA C layout
+//      (row p = 4*(lane>>4)+reg, column i = lane&15);
 //   5. gradient: acc^T[d][i] += X^T[d][p] * E'[p][i] — the accumulator tile E' is ALREADY in
 //      the B-operand layout of the next MFMA (it sums over E's row index p), so it never
 //      leaves registers; A = the same LDS tile read transposed (conflict-free ds_read_b32).
@@ -70,14 +71,16 @@ template <int NB, int WAVES, bool GRAD>
 __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
     using L = TileLds<NB, WAVES>;
     constexpr int SW = L::SW, DPAD = WAVES * SW;
-    constexpr bool RS = (WAVES == 8);      // reduce-scatter exchange: one S' element per lane of the workgroup
+    // reduce-scatter exchange: the S' tile is split over the lanes of the workgroup (EPL elements per lane)
+    constexpr bool RS = WAVES > 1;
+    constexpr int EPL = RS ? 8 / WAVES : 1;
+    static_assert(WAVES == 1 || WAVES == 4 || WAVES == 8, "1, 4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int my_t = wave & 1, my_r = (wave >> 1) & 3;     // RS: the row group / accumulator register this wave finishes
+    const int my_t = wave & 1, my_r = ((wave >> 1) * EPL) & 3;     // RS: the row group / first accumulator register this wave finishes
     const int i16 = lane & 15, g = lane >> 4;
     const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    f32x4* xch = reinterpret_cast<f32x4*>(smem + L::XCH_OFF);
     const float* xs = smem + wave * L::SLICE;
     const unsigned xs_byte = smem_byte + (unsigned)(wave * L::SLICE) * 4u;
 
@@ -234,12 +237,14 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 
         asm volatile("" ::"v"(s0), "v"(s1));
         PHASE_MARK(0);
-        f32x4 e0, e1;
+        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
         if constexpr (RS) {
-            // 3'. REDUCE-SCATTER exchange (8 waves): the 16 x 32 tile of S' has one element per lane of the workgroup.
-            //     Wave w finishes register r = w >> 1 of row group t = w & 1 only -- eight conflict-free scalar
-            //     reads instead of sixteen 16-byte ones, and one expm1 per lane instead of eight replicated in
-            //     every wave (VALU work issues through the same port as the MFMAs of the SIMD's other wave).
+            // 3'. REDUCE-SCATTER exchange: the 16 x 32 tile of S' is split over the lanes of the workgroup (one
+            //     element per lane with 8 waves, two with 4).  Wave w finishes registers r = EPL (w >> 1) ... of
+            //     row group t = w & 1 only -- conflict-free scalar reads instead of 16-byte ones from every wave,
+            //     and EPL expm1 per lane instead of eight replicated in every wave (VALU work issues through the
+            //     same port as the MFMAs of the SIMD's other wave: N = 32768, D = 1024 85.4 -> 77.7 ms,
+            //     D = 768 56.7 -> 54.4 ms, D = 256 22.0 -> 19.4 ms).
             //     Partials and E are stored component-major ([.][t][r][lane]).  Gradient instantiation: a second
             //     barrier publishes E, which also protects the single partial buffer; sum-only: buffers alternate.
             float* xp = smem + L::XCH_OFF + (GRAD ? 0 : buf * L::XCH_ONE);
@@ -252,34 +257,61 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const float* mine = xp + (my_t * 4 + my_r) * 64 + lane;
-            float sv = mine[0];
+            float sv[EPL];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) sv += mine[w * 512];      // fixed order: deterministic
+            for (int j = 0; j < EPL; ++j) {
+                const float* mine = xp + (my_t * 4 + my_r + j) * 64 + lane;
+                sv[j] = mine[0];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) sv[j] += mine[w * 512];      // fixed order: deterministic
+            }
             PHASE_MARK(1);
-            const float cnv = smem[L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g + my_r];
-            const float tv = fmaxf((cnv + rn_my - 2.f * sv) * a.inv_d2, 0.f);
-            EQ v_;
-            if (!__any(tv >= EM1_TINY)) {
-                v_ = em1_split_tiny(tv);
+            float tv[EPL], tmax = 0.f;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const float cnv = smem[L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g + my_r + j];
+                tv[j] = fmaxf((cnv + rn_my - 2.f * sv[j]) * a.inv_d2, 0.f);
+                tmax = fmaxf(tmax, tv[j]);
+            }
+            EQ v_[EPL];
+            if (!__any(tmax >= EM1_TINY)) {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) v_[j] = em1_split_tiny(tv[j]);
             } else {
-                v_ = em1_split(tv);
-                if (__any(tv >= EM1_POLY_MAX)) {
-                    if (tv >= EM1_POLY_MAX) { v_.e = expm1f(-tv); v_.q = v_.e + tv; }
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) v_[j] = em1_split(tv[j]);
+                if (__any(tmax >= EM1_POLY_MAX)) {
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j)
+                        if (tv[j] >= EM1_POLY_MAX) { v_[j].e = expm1f(-tv[j]); v_[j].q = v_[j].e + tv[j]; }
                 }
             }
-            if (any_invalid && !valid_my) { v_.e = 0.f; v_.q = 0.f; }
-            if (p0 + TILE_P > a.n_cols && p0 + 4 * g + my_r >= a.n_cols) { v_.e = 0.f; v_.q = 0.f; }
-            if (set) f1 = fmaf(wsym, v_.q, f1);
-            else f0 += v_.q;
-            const float es = __uint_as_float(__float_as_uint(v_.e) ^ (set ? 0x80000000u : 0u));   // s_p E
-            if (GRAD) fr0 += es;
+            if (any_invalid && !valid_my) {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) { v_[j].e = 0.f; v_[j].q = 0.f; }
+            }
+            if (p0 + TILE_P > a.n_cols) {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j)
+                    if (p0 + 4 * g + my_r + j >= a.n_cols) { v_[j].e = 0.f; v_[j].q = 0.f; }
+            }
+            float qs = v_[0].q, es[EPL];
+#pragma unroll
+            for (int j = 1; j < EPL; ++j) qs += v_[j].q;
+            if (set) f1 = fmaf(wsym, qs, f1);
+            else f0 += qs;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                es[j] = __uint_as_float(__float_as_uint(v_[j].e) ^ (set ? 0x80000000u : 0u));   // s_p E
+                if (GRAD) fr0 += es[j];
+            }
             if (((tile - tb) & 7) == 7) {
                 sum0 += (double)f0; sum1 += (double)f1; rowsum0 += (double)fr0;
                 f0 = f1 = fr0 = 0.f;
             }
             if (GRAD) {
-                eb[(my_t * 4 + my_r) * 64 + lane] = es;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) eb[(my_t * 4 + my_r + j) * 64 + lane] = es[j];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -290,30 +322,12 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
                 }
             }
         } else {
-            // 3. exchange the slice partials through LDS (raw s_barrier: no vmcnt drain); double buffered,
-            //    so one barrier per tile
-            //    (WAVES == 1: narrow latents — one wave holds the whole feature dimension, nothing to exchange)
-            if (WAVES > 1) {
-                f32x4* xb = xch + buf * (L::XCH_ONE / 4);
-                xb[(wave * 2 + 0) * 64 + lane] = s0;
-                xb[(wave * 2 + 1) * 64 + lane] = s1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                s0 = xb[(0 * 2 + 0) * 64 + lane];
-                s1 = xb[(0 * 2 + 1) * 64 + lane];
-    #pragma unroll
-                for (int w = 1; w < WAVES; ++w) {      // fixed order: identical in every wave, deterministic
-                    s0 += xb[(w * 2 + 0) * 64 + lane];
-                    s1 += xb[(w * 2 + 1) * 64 + lane];
-                }
-            }
-
+            // WAVES == 1 (narrow latents): one wave holds the whole feature dimension, nothing to exchange
             PHASE_MARK(1);
             // 4. E' = expm1(-t), t = (|x_p|^2 + |z_i|^2 - 2 S') / D^2 clamped at 0; register r <-> p = p0 + 4g + r
             const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + L::NORM_OFF + (buf * WAVES + wave) * TILE_P + 4 * g);
             f32x4 t0, t1, q0, q1;
-    #pragma unroll
+#pragma unroll
             for (int r = 0; r < 4; ++r) {
                 t0[r] = fmaxf((cn[r] + rn[0] - 2.f * s0[r]) * a.inv_d2, 0.f);
                 t1[r] = fmaxf((cn[r] + rn[1] - 2.f * s1[r]) * a.inv_d2, 0.f);
@@ -321,19 +335,19 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
             const float tmax = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])),
                                      fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
             if (!__any(tmax >= EM1_TINY)) {
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     { const EQ v_ = em1_split_tiny(t0[r]); e0[r] = v_.e; q0[r] = v_.q; }
                     { const EQ v_ = em1_split_tiny(t1[r]); e1[r] = v_.e; q1[r] = v_.q; }
                 }
             } else {
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     { const EQ v_ = em1_split(t0[r]); e0[r] = v_.e; q0[r] = v_.q; }
                     { const EQ v_ = em1_split(t1[r]); e1[r] = v_.e; q1[r] = v_.q; }
                 }
                 if (__any(tmax >= EM1_POLY_MAX)) {
-    #pragma unroll
+#pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (t0[r] >= EM1_POLY_MAX) { e0[r] = expm1f(-t0[r]); q0[r] = e0[r] + t0[r]; }
                         if (t1[r] >= EM1_POLY_MAX) { e1[r] = expm1f(-t1[r]); q1[r] = e1[r] + t1[r]; }
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
                 if (!valid_i[1]) { e1 = f32x4{0.f, 0.f, 0.f, 0.f}; q1 = e1; }
             }
             if (p0 + TILE_P > a.n_cols) {
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (p0 + 4 * g + r >= a.n_cols) { e0[r] = 0.f; e1[r] = 0.f; q0[r] = 0.f; q1[r] = 0.f; }
             }
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         __syncthreads();
         double* red = reinterpret_cast<double*>(smem + L::XCH_OFF);     // [WAVES][2] sums, then [WAVES][16] row sums
         if (lane == 0) { red[wave * 2 + 0] = w0; red[wave * 2 + 1] = w1; }
-        if (GRAD && g == 0) red[2 * WAVES + wave * 16 + i16] = r0v;      // row group my_t, row i16
+        if (GRAD && g == 0) red[2 * WAVES + wave * 16 + i16] = r0v;      // row group my_t = wave & 1, row i16
         __syncthreads();
         w0 = 0.0; w1 = 0.0;
         for (int w = 0; w < WAVES; ++w) { w0 += red[w * 2 + 0]; w1 += red[w * 2 + 1]; }
