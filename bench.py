@@ -217,6 +217,13 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if backend == "nccl":
+            # create the RCCL communicator and load its kernels OUTSIDE the timed region, whatever --warmup is
+            w8 = torch.zeros(3, dtype=torch.float64, device=device)
+            dist.all_reduce(w8)
+            wg = torch.empty((world * 4, 8), dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(wg, torch.zeros((4, 8), dtype=torch.float32, device=device))
+            torch.cuda.synchronize(device)
 
     B, S, d, n, L, cfg_id, label = CONFIGS[args.config]
     if B % world:
