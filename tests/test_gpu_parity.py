@@ -753,3 +753,80 @@ def test_mmd_far_apart_and_coincident_points(N, D, scale, dtype):
     else:
         assert abs(float(reg.detach())) <= 1e-9 and abs(ref) <= 1e-12       # MMD of a sample with itself is 0
         assert float(zt.grad.abs().max()) <= 1e-6 * max(np.abs(gref).max(), 1e-12) + 1e-12
+
+
+def _random_step_shapes(count, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        B = int(rs.randint(1, 40))
+        S = int(rs.randint(1, 24))
+        d = int(rs.choice([8, 24, 33, 64, 100, 256, 515]))
+        n = int(rs.randint(1, 12))
+        L = int(rs.choice([1, 2, 3, 7, 16, 33, 77, 100, 130, 200, 300])) if rs.rand() > 0.15 else d
+        dec = str(rs.choice(["", "no_norm"]))
+        out.append((B, S, d, n, L, dec))
+    return out
+
+
+@pytest.mark.parametrize("B,S,d,n,L,dec", _random_step_shapes(24, 20240607))
+def test_random_shapes_whole_step_against_fp64_oracle(B, S, d, n, L, dec):
+    """Seeded sweep over ragged shapes (odd widths, n > S, L == d identity decoder, single rows): forward
+    values and every gradient of  w * reg_loss + <recon, G0>  against the oracle evaluated in fp64."""
+    h, params, prior, g0 = orc.synth_inputs(B, S, d, n, L, 7, dec)
+    w = 0.37
+    vae = build_vae(d, L, n, dec, params, torch.float32, 1e-9)
+    ht = torch.from_numpy(h).to(dev()).requires_grad_(True)
+    out = vae(input_encoding=ht, true_samples=torch.from_numpy(prior).to(dev()))
+    (out.reg_loss * w + (out.reconstructed_encoding * torch.from_numpy(g0).to(dev())).sum()).backward()
+    h64 = h.astype(np.float64)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    pr64, g64 = prior.astype(np.float64), g0.astype(np.float64)
+    fwd = orc.bottleneck_forward(h64, p64, n, pr64, eps=1e-9)
+    ref = orc.bottleneck_backward(h64, p64, n, fwd, g64, reg_weight=w, prior=pr64)
+    n_eff = min(n, S)
+    assert relerr(out.latent.detach().cpu().numpy(), fwd["latent"]) <= F32_TOL
+    assert relerr(out.reconstructed_encoding.detach().cpu().numpy(), fwd["recon"]) <= F32_TOL
+    assert abs(float(out.reg_loss.detach()) - fwd["reg_loss"]) <= F32_TOL * abs(fwd["reg_loss"]) + 1e-12
+    got = dict(h=ht.grad, We=vae.encoder.token_to_latent.weight.grad, be=vae.encoder.token_to_latent.bias.grad)
+    if "Wd" in params:
+        got.update(Wd=vae.decoder.latent_to_token.weight.grad, bd=vae.decoder.latent_to_token.bias.grad)
+    if "gamma" in params:
+        got.update(gamma=vae.decoder.norm.weight.grad, beta=vae.decoder.norm.bias.grad)
+    for k, v in got.items():
+        assert relerr(v.cpu().numpy(), ref[k]) <= F32_TOL, k
+    assert n_eff == S or float(ht.grad[:, n_eff:].abs().max()) == 0.0
+
+
+def _random_block_shapes(count, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        N = int(rs.randint(2, 2600))
+        D = int(rs.choice([1, 4, 17, 64, 77, 81, 129, 192, 193, 255, 400, 513, 769, 1024, 1030]))
+        lo = int(rs.randint(0, N))
+        hi = int(rs.randint(lo + 1, N + 1))
+        out.append((N, D, lo, hi))
+    return out
+
+
+@pytest.mark.parametrize("N,D,lo,hi", _random_block_shapes(20, 77001))
+def test_random_row_blocks_against_fp64_oracle(N, D, lo, hi):
+    """Seeded sweep over kernel families and arbitrary (unaligned) row ranges: the three partial sums and the
+    gradient of the block's rows against the oracle in fp64."""
+    from transformer_vae_amd import functional as F
+    rs = np.random.RandomState(N * 31 + D)
+    z = np.tanh(rs.standard_normal((N, D))).astype(np.float32)
+    y = rs.standard_normal((N, D)).astype(np.float32)
+    zt, yt = torch.from_numpy(z).to(dev()), torch.from_numpy(y).to(dev())
+    rows = zt[lo:hi].clone().requires_grad_(True)
+    ls, gs = F.mmd_scales(7, 3, N, D)
+    loss, sums = F.mmd_row_block(rows, zt, yt, lo, ls, gs)
+    loss.backward()
+    z64, y64 = z.astype(np.float64), y.astype(np.float64)
+    s_zz, s_zy, s_yy = orc.mmd_partial_sums(z64[lo:hi], y64[lo:hi], z64, y64)
+    got = sums.cpu().numpy()
+    for g, r in zip(got, (s_zz, s_zy, s_yy)):
+        assert abs(g - r) <= 1e-6 * abs(r) + 1e-9, (got, (s_zz, s_zy, s_yy))
+    gref = orc.mmd_grad_latent_rows(z64[lo:hi], z64, y64) * (3.0 / 7.0)     # reg = MMD * n_latents / batch
+    assert relerr(rows.grad.cpu().numpy(), gref) <= F32_TOL
