@@ -235,6 +235,20 @@ def main():
 
     from transformer_vae_amd import _lib
     lib = _lib.lib()
+    # The launch-bound side configs run FIRST, in a fresh process state (measured: after the cfg4 workload and the
+    # CPU baseline's worker threads the same eager loop reads 0.37 ms instead of 0.26 ms per step).
+    others = None
+    if rank == 0 and world == 1 and not args.no_side_configs:
+        others = []
+        for name, graphed in (("cfg1", False), ("cfg1", True), ("cfg2", False), ("cfg2", True), ("cfg3", False)):
+            if name == args.config:
+                continue
+            try:
+                others.append(side_config(name, device, graphed))
+            except Exception as e:
+                others.append({"workload": name, "hip_graph": graphed, "value": None, "error": repr(e)[:200]})
+        torch.cuda.synchronize(device)
+        torch.cuda.empty_cache()
     mmd_bf16 = args.mmd_dtype == "bf16"
     vae = make_vae(d, L, n, device, dtype, "global" if world > 1 else "local", world,
                    torch.bfloat16 if mmd_bf16 else None)
@@ -279,7 +293,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    reg = float(out.reg_loss)
+    reg = float(out.reg_loss.detach())
     assert np.isfinite(reg) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
     assert h.grad is not None and h.grad.shape == h.shape
 
@@ -321,22 +335,14 @@ def main():
         "reg_loss": reg, "roofline": roofline,
     }
     if rank == 0:
+        if others is not None:
+            line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.config, world)
             except Exception as e:      # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e!r}"}
-        if world == 1 and not args.no_side_configs:
-            others = []
-            for name, graphed in (("cfg1", False), ("cfg1", True), ("cfg2", False), ("cfg2", True), ("cfg3", False)):
-                if name == args.config:
-                    continue
-                try:
-                    others.append(side_config(name, device, graphed))
-                except Exception as e:
-                    others.append({"workload": name, "hip_graph": graphed, "value": None, "error": repr(e)[:200]})
-            line["other_configs"] = others
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -830,3 +830,69 @@ def test_random_row_blocks_against_fp64_oracle(N, D, lo, hi):
         assert abs(g - r) <= 1e-6 * abs(r) + 1e-9, (got, (s_zz, s_zy, s_yy))
     gref = orc.mmd_grad_latent_rows(z64[lo:hi], z64, y64) * (3.0 / 7.0)     # reg = MMD * n_latents / batch
     assert relerr(rows.grad.cpu().numpy(), gref) <= F32_TOL
+
+
+@pytest.mark.parametrize("B,S,d,n,L,dec,dtype", [(8, 60, 512, 5, 77, "", torch.float32), (70, 30, 768, 5, 77, "no_norm", torch.float32),
+                                                 (6, 3, 64, 5, 33, "", torch.float32), (5, 9, 96, 4, 96, "", torch.float32),
+                                                 (16, 12, 256, 6, 300, "", torch.bfloat16)])
+def test_fused_step_equals_the_three_separate_nodes(B, S, d, n, L, dec, dtype):
+    """EncoderDecoderVAE.forward takes the one-node path for the stock pair; `fuse_step = False` keeps the three
+    autograd nodes.  Same kernels: outputs identical, gradients equal to rounding (one fused multiply-add),
+    including a cotangent on `latent` itself, a frozen input and frozen parameters."""
+    h, params, prior, g0 = orc.synth_inputs(B, S, d, n, L, 11, dec)
+    n_eff = min(n, S)
+    gl = torch.from_numpy(np.random.RandomState(5).standard_normal((B, n_eff, L)).astype(np.float32)).to(dev()) * 1e-3
+    res = []
+    for fuse, freeze in ((True, False), (False, False), (True, True), (False, True)):
+        vae = build_vae(d, L, n, dec, params, dtype, 1e-9)
+        vae.fuse_step = fuse
+        assert vae._can_fuse(torch.from_numpy(h).to(dev()).to(dtype), None) == fuse
+        ht = torch.from_numpy(h).to(dev()).to(dtype).requires_grad_(not freeze)
+        if freeze:
+            vae.encoder.token_to_latent.bias.requires_grad_(False)
+            if vae.decoder.latent_to_token is not None:
+                vae.decoder.latent_to_token.weight.requires_grad_(False)
+        out = vae(input_encoding=ht, true_samples=torch.from_numpy(prior).to(dev()))
+        assert out.latent.shape == (B, n_eff, L) and out.reconstructed_encoding.shape == (B, n_eff, d)
+        loss = out.reg_loss * 0.8 + (out.reconstructed_encoding.float() * torch.from_numpy(g0).to(dev())).sum() \
+            + (out.latent.float() * gl).sum()
+        loss.backward()
+        grads = {k: (None if p.grad is None else p.grad.float().cpu().numpy()) for k, p in vae.named_parameters()}
+        grads["h"] = None if ht.grad is None else ht.grad.float().cpu().numpy()
+        res.append((out.latent.detach().float().cpu().numpy(), out.reconstructed_encoding.detach().float().cpu().numpy(),
+                    float(out.reg_loss.detach()), grads))
+    tol = 1e-6 if dtype == torch.float32 else BF16_TOL
+    for a, b in ((res[0], res[1]), (res[2], res[3])):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        assert a[3].keys() == b[3].keys()
+        for k in a[3]:
+            assert (a[3][k] is None) == (b[3][k] is None), k
+            if a[3][k] is not None:
+                assert relerr(a[3][k], b[3][k]) <= tol, k
+    assert res[2][3]["h"] is None and res[2][3]["encoder.token_to_latent.bias"] is None
+
+
+def test_fused_step_is_bypassed_when_it_must_be():
+    """Hooks on the sub-modules, autocast, a given latent, skip_reg_loss and the t5_norm / identity decoders keep
+    the separate nodes (the fused node would hide them)."""
+    h, params, prior, g0 = orc.synth_inputs(4, 6, 32, 3, 11, 1, "")
+    vae = build_vae(32, 11, 3, "", params)
+    ht = torch.from_numpy(h).to(dev())
+    assert vae._can_fuse(ht, None)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not vae._can_fuse(ht, None)
+    assert not vae._can_fuse(ht.double(), None)
+    seen = []
+    hook = vae.encoder.register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    assert not vae._can_fuse(ht, None)
+    vae(input_encoding=ht)
+    assert seen == [(4, 3, 11)]
+    hook.remove()
+    assert vae._can_fuse(ht, None)
+    out = vae(input_encoding=ht, skip_reg_loss=True)
+    assert out.reg_loss.dtype == torch.int64 and int(out.reg_loss) == 0
+    h2, p2, _, _ = orc.synth_inputs(4, 8, 32, 2, 32, 2, "no_norm")
+    ident = build_vae(32, 32, 2, "no_norm", p2)
+    assert not ident._can_fuse(torch.from_numpy(h2).to(dev()), None)
+    out = ident(input_encoding=torch.from_numpy(h2).to(dev()))
+    assert out.reconstructed_encoding is out.latent

@@ -139,6 +139,50 @@ class EncoderDecoderVAE(nn.Module):
         self.mmd_scope = mmd_scope
         self.process_group = process_group
         self.compensate_ddp_mean = compensate_ddp_mean
+        # encode -> MMD -> decode as one autograd node when the stock pair is used plainly (same kernels and
+        # numbers; less Python autograd bookkeeping per eager step).  False keeps the three separate nodes.
+        self.fuse_step = True
+
+    def _can_fuse(self, h, true_samples):
+        enc, dec = self.encoder, self.decoder
+        if not self.fuse_step or type(enc) is not LatentEncoderNTokens \
+                or type(dec) not in (LatentDecoderNTokens, LatentDecoderFunnelNorm):
+            return False
+        if self.mmd_dtype is not None or torch.is_autocast_enabled() or not torch.is_tensor(h):
+            return False
+        if not h.is_cuda or h.dim() != 3 or h.dtype not in (torch.float32, torch.bfloat16):
+            return False
+        if h.shape[0] * min(int(enc.n_tokens), h.shape[1]) == 0 or h.shape[2] != enc.token_to_latent.weight.shape[1]:
+            return False
+        if dec.latent_to_token is None and not isinstance(dec, LatentDecoderFunnelNorm):
+            return False                      # identity decoder: reconstructed_encoding IS the latent tensor
+        for m in (enc, dec, enc.token_to_latent, dec.latent_to_token, getattr(dec, "norm", None)):
+            if m is not None and (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks
+                                  or m._backward_pre_hooks):
+                return False
+        if any(p.dtype != h.dtype for p in self.parameters()):
+            return False
+        if self.mmd_scope == "global":
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+                return False
+        return True
+
+    def _fused_forward(self, h, true_samples):
+        enc, dec = self.encoder, self.decoder
+        n_eff = min(int(enc.n_tokens), h.shape[1])
+        L = enc.token_to_latent.weight.shape[0]
+        if true_samples is None:
+            true_samples = torch.randn((h.shape[0] * n_eff, L), device=h.device)   # fp32, as the reference (:135)
+        else:
+            true_samples = true_samples.reshape(h.shape[0] * n_eff, L).to(h.device)
+        w, b = dec._linear_params()
+        norm = getattr(dec, "norm", None)
+        latent, recon, reg_loss = F.bottleneck_step(
+            h, enc.token_to_latent.weight, enc.token_to_latent.bias, w, b,
+            None if norm is None else norm.weight, None if norm is None else norm.bias, true_samples,
+            enc.n_tokens, 1e-5 if norm is None else norm.eps)
+        return BaseVAE_Output(latent=latent, reconstructed_encoding=recon, reg_loss=reg_loss)
 
     def _model_forward(self, encoding, latent=None):
         if latent is None:
@@ -149,6 +193,8 @@ class EncoderDecoderVAE(nn.Module):
         if input_encoding is None and latent is None:
             raise ValueError("Both `input_encoding` and `latent` sent to VAE are None.")
         use_reg_loss = self.use_reg_loss and latent is None and skip_reg_loss is False  # don't regularise if given latent
+        if use_reg_loss and self._can_fuse(input_encoding, true_samples):
+            return self._fused_forward(input_encoding, true_samples)
         recon_encoding, latent = self._model_forward(input_encoding, latent=latent)
         if use_reg_loss:
             # each token encoding is a separate latent code (autoencoders.py:110-112)

@@ -205,6 +205,117 @@ class _MMDRegulariser(torch.autograd.Function):
         return g, None, None, None, None, None
 
 
+class _BottleneckStep(torch.autograd.Function):
+    """encode -> MMD -> decode as ONE autograd node (the three classes above, back to back).
+
+    Same kernels, same numbers; what it saves is host time: a Python autograd.Function costs ~40 us of
+    bookkeeping per apply and per backward, which is most of an eager step at the reference's small batches
+    (BASELINE cfg1/cfg2).  Used by EncoderDecoderVAE.forward for the stock encoder/decoder pair when nothing
+    else (autocast, hooks, a sharded regulariser, a given latent) asks for the separate nodes."""
+
+    @staticmethod
+    def forward(ctx, h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float):
+        ctx.set_materialize_grads(False)
+        dt = h.dtype
+        hc = h if h.stride(2) == 1 else h.contiguous()
+        Wc, bc = We.contiguous(), be.contiguous()
+        B, S, d = hc.shape
+        L = Wc.shape[0]
+        n_eff = min(int(n_tokens), S)
+        N = B * n_eff
+        dev = h.device
+        lib = _lib.lib()
+        stream = _stream(hc)
+        code = _DTYPES[dt]
+        # --- encode (autoencoders.py:21-22)
+        z = torch.empty((B, n_eff, L), dtype=dt, device=dev)
+        ws = _workspace(lib.tvae_encode_fwd_workspace_bytes(B, n_eff, d, L), dev)
+        _lib.check(lib.tvae_encode_fwd(_ptr(hc), hc.stride(0), hc.stride(1), _ptr(Wc), _ptr(bc), _ptr(z),
+                                       B, n_eff, d, L, code, _ptr(ws), ws.numel(), stream), "tvae_encode_fwd")
+        # --- regulariser (autoencoders.py:110-112, 117-136); bf16 latents against an fp32 prior promote to fp32
+        mdt = torch.bfloat16 if (dt == torch.bfloat16 and prior.dtype == torch.bfloat16) else torch.float32
+        za = z.reshape(N, L).to(mdt)
+        ya = prior.reshape(N, L).to(mdt).contiguous()
+        want_grad = any(ctx.needs_input_grad[:3])
+        loss_scale, grad_scale = mmd_scales(B, n_eff, N, L)
+        ws_bytes = lib.tvae_mmd_workspace_bytes(N, N, L, int(want_grad))
+        if ws_bytes < 0:
+            raise RuntimeError(f"MMD regulariser: unsupported problem size (n_total={N}, D={L})")
+        ws = _workspace(ws_bytes, dev)
+        sums = torch.empty(3, dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dz_mmd = torch.empty((N, L), dtype=mdt, device=dev) if want_grad else None
+        _lib.check(lib.tvae_mmd_fwd_bwd(_ptr(za), _ptr(ya), N, 0, N, L, _DTYPES[mdt], _ptr(sums), _ptr(loss),
+                                        float(loss_scale), _ptr(dz_mmd), float(grad_scale), _ptr(ws), ws.numel(),
+                                        stream), "tvae_mmd_fwd_bwd")
+        # --- decode (autoencoders.py:38-39, 66-67)
+        has_lin, has_ln = Wd is not None, gamma is not None
+        Wdc = Wd.contiguous() if has_lin else None
+        bdc = bd.contiguous() if has_lin else None
+        gc = gamma.contiguous() if has_ln else None
+        btc = beta.contiguous() if has_ln else None
+        recon = torch.empty((N, d), dtype=dt, device=dev)
+        pre = torch.empty((N, d), dtype=dt, device=dev) if (has_lin and has_ln) else None
+        mean = torch.empty((N,), dtype=torch.float32, device=dev) if has_ln else None
+        rstd = torch.empty((N,), dtype=torch.float32, device=dev) if has_ln else None
+        ws = _workspace(lib.tvae_decode_fwd_workspace_bytes(N, L, d), dev)
+        _lib.check(lib.tvae_decode_fwd(_ptr(z), _ptr(Wdc), _ptr(bdc), _ptr(gc), _ptr(btc), float(eps), _ptr(recon),
+                                       _ptr(pre), _ptr(mean), _ptr(rstd), N, L, d, code, _ptr(ws), ws.numel(),
+                                       stream), "tvae_decode_fwd")
+        ctx.save_for_backward(hc, Wc, z, Wdc, gc, pre, mean, rstd, dz_mmd)
+        ctx.meta = (B, S, d, L, n_eff, dt)
+        return z, recon.view(B, n_eff, d), loss
+
+    @staticmethod
+    def backward(ctx, g_latent, g_recon, g_reg):
+        hc, Wc, z, Wdc, gc, pre, mean, rstd, dz_mmd = ctx.saved_tensors
+        B, S, d, L, n_eff, dt = ctx.meta
+        N = B * n_eff
+        need = ctx.needs_input_grad
+        dev = hc.device
+        lib = _lib.lib()
+        stream = _stream(hc)
+        code = _DTYPES[dt]
+        has_lin, has_ln = Wdc is not None, gc is not None
+        want_z = any(need[:3])
+        dz = dWd = dbd = dgamma = dbeta = None
+        if g_recon is not None:
+            dc = g_recon.to(dt).reshape(N, d).contiguous()
+            dz = torch.empty((N, L), dtype=dt, device=dev) if want_z else None
+            dWd = torch.empty((d, L), dtype=dt, device=dev) if (has_lin and need[3]) else None
+            dbd = torch.empty((d,), dtype=dt, device=dev) if (has_lin and need[4]) else None
+            want_ln = has_ln and (need[5] or need[6])
+            dgamma = torch.empty((d,), dtype=dt, device=dev) if want_ln else None
+            dbeta = torch.empty((d,), dtype=dt, device=dev) if want_ln else None
+            ws = _workspace(lib.tvae_decode_bwd_workspace_bytes(N, L, d), dev)
+            _lib.check(lib.tvae_decode_bwd(_ptr(dc), _ptr(z), _ptr(Wdc), _ptr(gc), _ptr(pre), _ptr(mean), _ptr(rstd),
+                                           _ptr(dz), _ptr(dWd), _ptr(dbd), _ptr(dgamma), _ptr(dbeta), N, L, d, code,
+                                           _ptr(ws), ws.numel(), stream), "tvae_decode_bwd")
+        dh = dWe = dbe = None
+        if want_z:
+            # d latent = decoder's share + the regulariser's (scaled by its upstream gradient) + a direct one
+            if g_reg is not None and dz_mmd is not None:
+                gm = g_reg.to(dz_mmd.dtype)
+                if dz is None:
+                    dz = (dz_mmd * gm).to(dt)
+                elif dz_mmd.dtype == dt:
+                    dz = torch.addcmul(dz, dz_mmd, gm)
+                else:
+                    dz = torch.addcmul(dz.to(dz_mmd.dtype), dz_mmd, gm).to(dt)
+            if g_latent is not None:
+                gl = g_latent.to(dt).reshape(N, L)
+                dz = gl.contiguous() if dz is None else dz + gl
+            if dz is not None:
+                dh = torch.empty((B, S, d), dtype=dt, device=dev) if need[0] else None
+                dWe = torch.empty((L, d), dtype=dt, device=dev) if need[1] else None
+                dbe = torch.empty((L,), dtype=dt, device=dev) if need[2] else None
+                ws = _workspace(lib.tvae_encode_bwd_workspace_bytes(B, n_eff, d, L), dev)
+                _lib.check(lib.tvae_encode_bwd(_ptr(dz), _ptr(z), _ptr(hc), hc.stride(0), hc.stride(1), _ptr(Wc),
+                                               _ptr(dh), _ptr(dWe), _ptr(dbe), B, S, n_eff, d, L, code,
+                                               _ptr(ws), ws.numel(), stream), "tvae_encode_bwd")
+        return dh, dWe, dbe, dWd, dbd, dgamma, dbeta, None, None, None
+
+
 class _Upsample(torch.autograd.Function):
     """HF funnel `upsample` as used on reconstructed_encoding (reference: model.py:265-271)."""
 
@@ -269,6 +380,11 @@ def mmd_reg_loss(latent2d, prior, batch_size: int, n_latents: int):
 def mmd_row_block(z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float):
     """Row-sharded building block: returns (local loss share, float64[3] partial sums)."""
     return _MMDRegulariser.apply(z_rows, z_all, y_all, int(row_offset), float(loss_scale), float(grad_scale))
+
+
+def bottleneck_step(h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float):
+    """(latent, reconstructed_encoding, reg_loss) of the stock bottleneck as one autograd node."""
+    return _BottleneckStep.apply(h, We, be, Wd, bd, gamma, beta, prior, int(n_tokens), float(eps))
 
 
 def upsample(x, stride: int, target_len: int, separate_cls: bool = True, truncate_seq: bool = False):
