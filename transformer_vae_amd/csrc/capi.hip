@@ -112,27 +112,29 @@ extern "C" int tvae_encode_bwd(const void* d_latent, const void* latent, const v
                     (long long)ar.off);
 
     TVAE_PROPAGATE(tanh_bwd(d_latent, latent, dpre, rows * L, dtype, s));
+    GemmDesc gh{}, gw{};
     if (dh) {
         // rows >= n_eff of every sequence: exact zeros (slice backward); rows < n_eff: d_pre @ We
         TVAE_PROPAGATE(zero_tail_rows(dh, B, S, n_eff, d, dtype, s));
-        GemmDesc g{};
+        GemmDesc& g = gh;
         g.A = dpre; g.B = We; g.C = dh; g.M = (int)rows; g.N = (int)d; g.K = (int)L;
         g.a_kmajor = false; g.b_kmajor = true;
         g.amap = dense_rows(L); g.bmap = dense_rows(d);
         g.cmap = RowMap{S * d, d, (int)n_eff};
         g.epilogue = EPI_NONE; g.dtype = dtype; g.slab = slab2; g.slab_floats = slab_dh;
-        TVAE_PROPAGATE(gemm_launch(g, s));
     }
     if (dWe) {
-        GemmDesc g{};
+        GemmDesc& g = gw;
         g.A = dpre; g.B = h; g.C = dWe; g.M = (int)L; g.N = (int)d; g.K = (int)rows;
         g.a_kmajor = true; g.b_kmajor = true;
         g.amap = dense_rows(L);
         g.bmap = RowMap{h_stride_b, h_stride_s, (int)n_eff};
         g.cmap = dense_rows(d);
         g.epilogue = EPI_NONE; g.dtype = dtype; g.slab = slab1; g.slab_floats = slab_we;
-        TVAE_PROPAGATE(gemm_launch(g, s));
     }
+    if (dh && dWe) TVAE_PROPAGATE(gemm_launch_pair(gh, gw, s));
+    else if (dh) TVAE_PROPAGATE(gemm_launch(gh, s));
+    else if (dWe) TVAE_PROPAGATE(gemm_launch(gw, s));
     if (dbe) TVAE_PROPAGATE(colsum(dpre, rows, L, dbe, dtype, colscratch, s));
     return TVAE_OK;
 }
@@ -223,22 +225,24 @@ extern "C" int tvae_decode_bwd(const void* d_recon, const void* latent, const vo
         }
         return TVAE_OK;
     }
+    GemmDesc gz{}, gw{};
     if (d_latent) {
-        GemmDesc g{};
+        GemmDesc& g = gz;
         g.A = dr; g.B = Wd; g.C = d_latent; g.M = (int)N; g.N = (int)L; g.K = (int)d;
         g.a_kmajor = false; g.b_kmajor = true;
         g.amap = dense_rows(d); g.bmap = dense_rows(L); g.cmap = dense_rows(L);
         g.epilogue = EPI_NONE; g.dtype = dtype; g.slab = slab2; g.slab_floats = slab_dz;
-        TVAE_PROPAGATE(gemm_launch(g, s));
     }
     if (dWd) {
-        GemmDesc g{};
+        GemmDesc& g = gw;
         g.A = dr; g.B = latent; g.C = dWd; g.M = (int)d; g.N = (int)L; g.K = (int)N;
         g.a_kmajor = true; g.b_kmajor = true;
         g.amap = dense_rows(d); g.bmap = dense_rows(L); g.cmap = dense_rows(L);
         g.epilogue = EPI_NONE; g.dtype = dtype; g.slab = slab1; g.slab_floats = slab_wd;
-        TVAE_PROPAGATE(gemm_launch(g, s));
     }
+    if (d_latent && dWd) TVAE_PROPAGATE(gemm_launch_pair(gz, gw, s));
+    else if (d_latent) TVAE_PROPAGATE(gemm_launch(gz, s));
+    else if (dWd) TVAE_PROPAGATE(gemm_launch(gw, s));
     if (dbd) TVAE_PROPAGATE(colsum(dr, N, d, dbd, dtype, colscratch, s));
     return TVAE_OK;
 }

@@ -75,13 +75,12 @@ __device__ __forceinline__ void tile_store(float (*tile)[LDS_LD], const float v[
 }
 
 template <typename T, bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
-    __shared__ float As[BK][LDS_LD];
-    __shared__ float Bs[BK][LDS_LD];
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by, int bz, float (*As)[LDS_LD],
+                                               float (*Bs)[LDS_LD]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int i32 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+    const int m0 = by * BM, n0 = bx * BN, z = bz;
     const int kbeg = z * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const T* __restrict__ A = static_cast<const T*>(a.A);
@@ -131,10 +130,40 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
     }
 }
 
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
+    __shared__ float As[BK][LDS_LD];
+    __shared__ float Bs[BK][LDS_LD];
+    gemm_tile_body<T, A_KMAJOR, B_KMAJOR, EPI>(a, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Two independent products in ONE launch (the two backward products of a projection: the activation gradient
+// dX = dY W, layouts <row-major, k-major>, and the weight gradient dW = dY^T X, layouts <k-major, k-major>).
+// At the reference's batch sizes each fills a fraction of the chip for ~10 us; side by side they cost one.
+struct GemmPairArgs {
+    GemmArgs p[2];
+    int gx[2], gy[2], nblk0;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPairArgs q) {
+    __shared__ float As[BK][LDS_LD];
+    __shared__ float Bs[BK][LDS_LD];
+    int b = blockIdx.x;
+    if (b < q.nblk0) {
+        const int bx = b % q.gx[0], t = b / q.gx[0];
+        gemm_tile_body<T, false, true, EPI_NONE>(q.p[0], bx, t % q.gy[0], t / q.gy[0], As, Bs);
+    } else {
+        b -= q.nblk0;
+        const int bx = b % q.gx[1], t = b / q.gx[1];
+        gemm_tile_body<T, true, true, EPI_NONE>(q.p[1], bx, t % q.gy[1], t / q.gy[1], As, Bs);
+    }
+}
+
 template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(GemmArgs a) {
+__device__ __forceinline__ void reduce_slabs_body(const GemmArgs& a, long long first, long long stride) {
     const long long total = (long long)a.M * a.N;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    for (long long idx = first; idx < total; idx += stride) {
         const int m = (int)(idx / a.N), n = (int)(idx % a.N);
         float v = 0.f;
         for (int z = 0; z < a.splits; ++z) v += a.slab[(long long)z * total + idx];
@@ -142,6 +171,20 @@ __global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(GemmArgs a) {
         if (EPI == EPI_BIAS_TANH) v = tanhf(v);
         static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
     }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(GemmArgs a) {
+    reduce_slabs_body<T, EPI>(a, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+}
+
+// slab sums of both products of a pair: the first nblk0 workgroups take product 0
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(GemmPairArgs q) {
+    const int b = blockIdx.x;
+    if (b < q.nblk0) reduce_slabs_body<T, EPI_NONE>(q.p[0], (long long)b * 256 + threadIdx.x, (long long)q.nblk0 * 256);
+    else reduce_slabs_body<T, EPI_NONE>(q.p[1], (long long)(b - q.nblk0) * 256 + threadIdx.x,
+                                        (long long)(gridDim.x - q.nblk0) * 256);
 }
 
 void choose_split(int M, int N, int K, int* splits, int* k_per_split) {
@@ -208,12 +251,77 @@ int64_t gemm_slab_floats(int M, int N, int K) {
     return s > 1 ? (int64_t)s * M * N : 0;
 }
 
+namespace {
+int prepare_args(const GemmDesc& g, GemmArgs& a);
+}
+
 int gemm_launch(const GemmDesc& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0) return TVAE_OK;
+    GemmArgs a;
+    TVAE_PROPAGATE(prepare_args(g, a));
+    if (g.dtype == TVAE_F32) return launch_typed<float>(g, a, stream);
+    if (g.dtype == TVAE_BF16) return launch_typed<bf16>(g, a, stream);
+    return fail(TVAE_ERR_ARG, "gemm: unknown dtype %d", g.dtype);
+}
+
+namespace {
+template <typename T>
+int launch_pair_typed(const GemmPairArgs& q, int nblk, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_pair_kernel<T>), dim3(nblk), dim3(256), 0, s, q);
+    const GemmArgs& a0 = q.p[0];
+    const GemmArgs& a1 = q.p[1];
+    auto rblocks = [](const GemmArgs& a) {
+        const long long total = (long long)a.M * a.N;
+        long long b = (total + 255) / 256;
+        return (int)(b > 2048 ? 2048 : b);
+    };
+    if (a0.splits > 1 && a1.splits > 1) {
+        GemmPairArgs r = q;
+        r.nblk0 = rblocks(a0);
+        hipLaunchKernelGGL((gemm_reduce_pair_kernel<T>), dim3(r.nblk0 + rblocks(a1)), dim3(256), 0, s, r);
+    } else if (a0.splits > 1) {
+        hipLaunchKernelGGL((gemm_reduce_slabs_kernel<T, EPI_NONE>), dim3(rblocks(a0)), dim3(256), 0, s, a0);
+    } else if (a1.splits > 1) {
+        hipLaunchKernelGGL((gemm_reduce_slabs_kernel<T, EPI_NONE>), dim3(rblocks(a1)), dim3(256), 0, s, a1);
+    }
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+}  // namespace
+
+// g0: activation gradient (A row-major, B k-major), g1: weight gradient (A and B k-major), both without epilogue
+// and of one dtype.  Small launches share one grid; large ones (or other layouts) go out one after the other.
+int gemm_launch_pair(const GemmDesc& g0, const GemmDesc& g1, hipStream_t stream) {
+    const bool shapes_ok = g0.M > 0 && g0.N > 0 && g1.M > 0 && g1.N > 0;
+    const bool layouts_ok = !g0.a_kmajor && g0.b_kmajor && g1.a_kmajor && g1.b_kmajor &&
+                            g0.epilogue == EPI_NONE && g1.epilogue == EPI_NONE && g0.dtype == g1.dtype;
+    if (shapes_ok && layouts_ok) {
+        GemmPairArgs q;
+        TVAE_PROPAGATE(prepare_args(g0, q.p[0]));
+        TVAE_PROPAGATE(prepare_args(g1, q.p[1]));
+        long long nb[2];
+        const GemmDesc* gs[2] = {&g0, &g1};
+        for (int i = 0; i < 2; ++i) {
+            q.gx[i] = (gs[i]->N + BN - 1) / BN;
+            q.gy[i] = (gs[i]->M + BM - 1) / BM;
+            nb[i] = (long long)q.gx[i] * q.gy[i] * q.p[i].splits;
+        }
+        if (nb[0] + nb[1] <= 4096) {
+            q.nblk0 = (int)nb[0];
+            if (g0.dtype == TVAE_F32) return launch_pair_typed<float>(q, (int)(nb[0] + nb[1]), stream);
+            if (g0.dtype == TVAE_BF16) return launch_pair_typed<bf16>(q, (int)(nb[0] + nb[1]), stream);
+            return fail(TVAE_ERR_ARG, "gemm: unknown dtype %d", g0.dtype);
+        }
+    }
+    TVAE_PROPAGATE(gemm_launch(g0, stream));
+    return gemm_launch(g1, stream);
+}
+
+namespace {
+int prepare_args(const GemmDesc& g, GemmArgs& a) {
     TVAE_REQUIRE(g.K > 0, "gemm: K must be positive (got %d)", g.K);
     TVAE_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
     TVAE_REQUIRE(g.epilogue == EPI_NONE || g.bias, "gemm: epilogue needs a bias pointer");
-    GemmArgs a;
     a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.slab = g.slab;
     a.M = g.M; a.N = g.N; a.K = g.K;
     a.amap = g.amap; a.bmap = g.bmap; a.cmap = g.cmap;
@@ -225,9 +333,8 @@ int gemm_launch(const GemmDesc& g, hipStream_t stream) {
     const size_t align = g.dtype == TVAE_F32 ? 16 : 8;
     a.vecA = g.amap.vec_ok() && (reinterpret_cast<uintptr_t>(g.A) % align == 0);
     a.vecB = g.bmap.vec_ok() && (reinterpret_cast<uintptr_t>(g.B) % align == 0);
-    if (g.dtype == TVAE_F32) return launch_typed<float>(g, a, stream);
-    if (g.dtype == TVAE_BF16) return launch_typed<bf16>(g, a, stream);
-    return fail(TVAE_ERR_ARG, "gemm: unknown dtype %d", g.dtype);
+    return TVAE_OK;
 }
+}  // namespace
 
 }  // namespace tvae

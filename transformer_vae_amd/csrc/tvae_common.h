@@ -107,6 +107,8 @@ struct GemmDesc {
 };
 int64_t gemm_slab_floats(int M, int N, int K);
 int gemm_launch(const GemmDesc& g, hipStream_t stream);
+// activation-gradient + weight-gradient products of one projection; one launch when both are small
+int gemm_launch_pair(const GemmDesc& g_act, const GemmDesc& g_weight, hipStream_t stream);
 
 // row-wise / column-wise helpers (rowops.hip)
 int layernorm_fwd(const void* r, const void* gamma, const void* beta, float eps, void* out,
