@@ -77,6 +77,11 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
     static_assert(WAVES == 1 || WAVES == 4 || WAVES == 8, "1, 4 or 8 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    // Single-wave workgroups: two waves per SIMD already saturate the matrix cores, and the dispatcher does not
+    // balance a third one (HW_ID dump at N = 5 120, D = 77: three waves on 102 SIMDs, one on 230; a wave alone
+    // on its SIMD finishes in 100 us, one of two in ~150, one of three in ~200).  Touching v175 makes the
+    // register footprint 176 = at most two waves per SIMD (kernel 187 -> 176 us there, neutral elsewhere).
+    if constexpr (WAVES == 1) asm volatile("" ::: "v175");
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int my_t = wave & 1, my_r = ((wave >> 1) * EPL) & 3;     // RS: the row group / first accumulator register this wave finishes
     const int i16 = lane & 15, g = lane >> 4;
