@@ -532,11 +532,13 @@ __global__ __launch_bounds__(1024) void mmd_moments_kernel(const float* __restri
     const int c = blockIdx.x * 64 + cx;
     double cz = 0.0, cy = 0.0, czl = 0.0, cyl = 0.0;
     if (c < DPAD) {
-        for (int w = ry; w < nwaves; w += 16) {
+#pragma unroll 8
+        for (int w = ry; w < nwaves; w += 16) {      // eight independent loads in flight per lane
             const double vz = (double)colpart[(long long)w * DPAD + c];
             const double vy = (double)colpart[((long long)nwaves + w) * DPAD + c];
+            const bool local = w >= nw0 && w < nw0 + nw1;
             cz += vz; cy += vy;
-            if (w >= nw0 && w < nw0 + nw1) { czl += vz; cyl += vy; }
+            czl += local ? vz : 0.0; cyl += local ? vy : 0.0;
         }
     }
     red[0][ry][cx] = cz; red[1][ry][cx] = cy; red[2][ry][cx] = czl; red[3][ry][cx] = cyl;
@@ -626,6 +628,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
         const int row = (int)(idx / f.D), c = (int)(idx - (long long)row * f.D);
         double rsum = 0.0;
         float gsum = 0.f;
+#pragma unroll 4
         for (int s = 0; s < f.col_splits; ++s) {
             rsum += f.wg_rowsum[(long long)s * f.n_rows_pad + row];
             gsum += f.wg_grad[((long long)s * f.n_rows_pad + row) * f.DPAD + c];
