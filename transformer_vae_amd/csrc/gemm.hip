@@ -166,7 +166,8 @@ __device__ __forceinline__ void reduce_slabs_body(const GemmArgs& a, long long f
     for (long long idx = first; idx < total; idx += stride) {
         const int m = (int)(idx / a.N), n = (int)(idx % a.N);
         float v = 0.f;
-        for (int z = 0; z < a.splits; ++z) v += a.slab[(long long)z * total + idx];
+#pragma unroll 8
+        for (int z = 0; z < a.splits; ++z) v += a.slab[(long long)z * total + idx];      // loads of 8 slabs in flight
         if (EPI != EPI_NONE) v += to_f32(static_cast<const T*>(a.bias)[n]);
         if (EPI == EPI_BIAS_TANH) v = tanhf(v);
         static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
