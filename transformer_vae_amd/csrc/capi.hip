@@ -43,6 +43,17 @@ struct Sizer {
 
 inline bool dtype_ok(int dtype) { return dtype == TVAE_F32 || dtype == TVAE_BF16; }
 
+// The bias gradient rides in the weight-gradient product (GemmDesc::colsum_out: one virtual column of ones)
+// when that column is cheap: it shares the last 64-column tile of the weight gradient, or the product is small
+// (at the reference's batch sizes a separate column reduction costs two more launches than it has work for).
+inline bool fuse_bias_grad(int64_t n_cols, int64_t k_rows) { return n_cols % 64 != 0 || k_rows <= 16384; }
+// split-K slabs of a weight-gradient product that may carry the bias column (the split count depends on the
+// number of column tiles, so cover both widths)
+inline int64_t wgrad_slab_floats(int64_t M, int64_t N, int64_t K) {
+    const int64_t a = gemm_slab_floats((int)M, (int)N, (int)K), b = gemm_slab_floats((int)M, (int)N + 1, (int)K);
+    return a > b ? a : b;
+}
+
 }  // namespace
 }  // namespace tvae
 
@@ -83,7 +94,7 @@ extern "C" int64_t tvae_encode_bwd_workspace_bytes(int64_t B, int64_t n_eff, int
     const int64_t rows = B * n_eff;
     Sizer s;
     s.take(rows * L * 4);                                              // d_pre
-    s.take(gemm_slab_floats((int)L, (int)d, (int)rows) * 4);           // dWe split-K slabs
+    s.take(wgrad_slab_floats(L, d, rows) * 4);                         // dWe split-K slabs (+ the dbe column)
     s.take(gemm_slab_floats((int)rows, (int)d, (int)L) * 4);           // dh slabs (normally 0)
     s.take(colreduce_scratch_floats(rows, L) * 4);                     // dbe partials
     return s.off;
@@ -102,7 +113,7 @@ extern "C" int tvae_encode_bwd(const void* d_latent, const void* latent, const v
     TVAE_REQUIRE(rows < (1ll << 31), "encode_bwd: too many rows");
     Arena ar(workspace, workspace_bytes);
     void* dpre = ar.take(rows * L * 4);
-    const int64_t slab_we = gemm_slab_floats((int)L, (int)d, (int)rows);
+    const int64_t slab_we = wgrad_slab_floats(L, d, rows);
     float* slab1 = static_cast<float*>(ar.take(slab_we * 4));
     const int64_t slab_dh = gemm_slab_floats((int)rows, (int)d, (int)L);
     float* slab2 = static_cast<float*>(ar.take(slab_dh * 4));
@@ -131,6 +142,7 @@ extern "C" int tvae_encode_bwd(const void* d_latent, const void* latent, const v
         g.bmap = RowMap{h_stride_b, h_stride_s, (int)n_eff};
         g.cmap = dense_rows(d);
         g.epilogue = EPI_NONE; g.dtype = dtype; g.slab = slab1; g.slab_floats = slab_we;
+        if (dbe && fuse_bias_grad(d, rows)) { g.colsum_out = dbe; dbe = nullptr; }   // dbe = dpre^T 1
     }
     if (dh && dWe) TVAE_PROPAGATE(gemm_launch_pair(gh, gw, s));
     else if (dh) TVAE_PROPAGATE(gemm_launch(gh, s));
@@ -181,9 +193,9 @@ extern "C" int tvae_decode_fwd(const void* latent, const void* Wd, const void* b
 extern "C" int64_t tvae_decode_bwd_workspace_bytes(int64_t N, int64_t L, int64_t d) {
     Sizer s;
     s.take(N * d * 4);                                              // dr
-    s.take(gemm_slab_floats((int)d, (int)L, (int)N) * 4);           // dWd slabs
+    s.take(wgrad_slab_floats(d, L, N) * 4);                         // dWd slabs (+ the dbd column)
     s.take(gemm_slab_floats((int)N, (int)L, (int)d) * 4);           // d_latent slabs
-    s.take(2 * colreduce_scratch_floats(N, d) * 4);                 // dgamma/dbeta or dbd partials
+    s.take(layernorm_bwd_scratch_floats(N, d) * 4);                 // dgamma/dbeta or dbd partials
     return s.off;
 }
 
@@ -202,20 +214,25 @@ extern "C" int tvae_decode_bwd(const void* d_recon, const void* latent, const vo
     TVAE_REQUIRE((!dgamma && !dbeta) || (gamma && dgamma && dbeta), "decode_bwd: dgamma/dbeta come as a pair, with gamma");
     Arena ar(workspace, workspace_bytes);
     void* dr_buf = ar.take(N * d * 4);
-    const int64_t slab_wd = gemm_slab_floats((int)d, (int)L, (int)N);
+    const int64_t slab_wd = wgrad_slab_floats(d, L, N);
     float* slab1 = static_cast<float*>(ar.take(slab_wd * 4));
     const int64_t slab_dz = gemm_slab_floats((int)N, (int)L, (int)d);
     float* slab2 = static_cast<float*>(ar.take(slab_dz * 4));
-    float* colscratch = static_cast<float*>(ar.take(2 * colreduce_scratch_floats(N, d) * 4));
+    float* colscratch = static_cast<float*>(ar.take(layernorm_bwd_scratch_floats(N, d) * 4));
     if (!ar.ok)
         return fail(TVAE_ERR_WORKSPACE, "decode_bwd: workspace %lld B < required %lld B", (long long)workspace_bytes,
                     (long long)ar.off);
 
     const void* dr = d_recon;
     if (gamma) {
-        if (dgamma) TVAE_PROPAGATE(layernorm_bwd_params(d_recon, ln_in, mean, rstd, dgamma, dbeta, N, d, dtype, colscratch, s));
         void* dst = (!Wd && d_latent) ? d_latent : dr_buf;   // identity decoder: LN backward IS d_latent
-        TVAE_PROPAGATE(layernorm_bwd_rows(d_recon, ln_in, mean, rstd, gamma, dst, N, d, dtype, s));
+        if (dgamma && layernorm_bwd_can_fuse(d_recon, ln_in, gamma, dst, d, dtype)) {
+            TVAE_PROPAGATE(layernorm_bwd_fused(d_recon, ln_in, mean, rstd, gamma, dst, dgamma, dbeta, N, d, dtype,
+                                               colscratch, s));
+        } else {
+            if (dgamma) TVAE_PROPAGATE(layernorm_bwd_params(d_recon, ln_in, mean, rstd, dgamma, dbeta, N, d, dtype, colscratch, s));
+            TVAE_PROPAGATE(layernorm_bwd_rows(d_recon, ln_in, mean, rstd, gamma, dst, N, d, dtype, s));
+        }
         dr = dst;
     }
     if (!Wd) {
@@ -239,6 +256,7 @@ extern "C" int tvae_decode_bwd(const void* d_recon, const void* latent, const vo
         g.a_kmajor = true; g.b_kmajor = true;
         g.amap = dense_rows(d); g.bmap = dense_rows(L); g.cmap = dense_rows(L);
         g.epilogue = EPI_NONE; g.dtype = dtype; g.slab = slab1; g.slab_floats = slab_wd;
+        if (dbd && fuse_bias_grad(L, N)) { g.colsum_out = dbd; dbd = nullptr; }      // dbd = dr^T 1
     }
     if (d_latent && dWd) TVAE_PROPAGATE(gemm_launch_pair(gz, gw, s));
     else if (d_latent) TVAE_PROPAGATE(gemm_launch(gz, s));

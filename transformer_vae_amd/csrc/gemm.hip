@@ -25,6 +25,9 @@ struct GemmArgs {
     int M, N, K, k_per_split, splits;
     RowMap amap, bmap, cmap;
     int vecA, vecB;
+    // weight-gradient products only (A and B k-major): B gets a virtual column of ones at index Nb (= N - 1), so
+    // that output column Nb is the column sum of A over k = the bias gradient, written to csum[m] instead of C
+    void* csum; int Nb;
 };
 
 // A (64 rows x 32 k) operand tile travels global -> registers -> LDS (as tile[k][row]) in two halves,
@@ -53,6 +56,20 @@ __device__ __forceinline__ void tile_load(float v[2][4], const T* __restrict__ P
                 const int nv = min(4, R - r);
                 if (vec && nv == 4) load4_vec(p, v[j]); else load4_guard(p, nv, v[j]);
             }
+        }
+    }
+}
+
+// the virtual ones column of a k-major B tile (see GemmArgs::csum): element (k, Nb) = 1 for k < kend
+__device__ __forceinline__ void tile_ones(float v[2][4], int r0, int Nb, int k0, int kend, int tid) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + 256 * j;
+        const int krow = q >> 4, rq = (q & 15) * 4;
+        const int e = Nb - (r0 + rq);
+        if (k0 + krow < kend && e >= 0 && e < 4) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[j][t] = (t == e) ? 1.f : v[j][t];
         }
     }
 }
@@ -90,16 +107,21 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    constexpr bool CSUM = A_KMAJOR && B_KMAJOR && EPI == EPI_NONE;   // the weight-gradient instantiation
+    const bool csum = CSUM && a.csum != nullptr;
+    const int nb_real = csum ? a.Nb : a.N;                            // columns B really has
     float ra[2][4], rb[2][4];
     tile_load<T, A_KMAJOR>(ra, A, a.amap, m0, a.M, kbeg, kend, a.vecA, tid);
-    tile_load<T, B_KMAJOR>(rb, B, a.bmap, n0, a.N, kbeg, kend, a.vecB, tid);
+    tile_load<T, B_KMAJOR>(rb, B, a.bmap, n0, nb_real, kbeg, kend, a.vecB, tid);
+    if (CSUM && csum) tile_ones(rb, n0, a.Nb, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         tile_store<A_KMAJOR>(As, ra, tid);
         tile_store<B_KMAJOR>(Bs, rb, tid);
         __syncthreads();
         if (k0 + BK < kend) {      // next tile's loads fly during this tile's MFMAs
             tile_load<T, A_KMAJOR>(ra, A, a.amap, m0, a.M, k0 + BK, kend, a.vecA, tid);
-            tile_load<T, B_KMAJOR>(rb, B, a.bmap, n0, a.N, k0 + BK, kend, a.vecB, tid);
+            tile_load<T, B_KMAJOR>(rb, B, a.bmap, n0, nb_real, k0 + BK, kend, a.vecB, tid);
+            if (CSUM && csum) tile_ones(rb, n0, a.Nb, k0 + BK, kend, tid);
         }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
@@ -125,7 +147,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by
         } else {
             if (EPI != EPI_NONE) v += bias;
             if (EPI == EPI_BIAS_TANH) v = tanhf(v);
-            static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
+            if (CSUM && csum && n == a.Nb) static_cast<T*>(a.csum)[m] = from_f32<T>(v);
+            else static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
         }
     }
 }
@@ -170,7 +193,8 @@ __device__ __forceinline__ void reduce_slabs_body(const GemmArgs& a, long long f
         for (int z = 0; z < a.splits; ++z) v += a.slab[(long long)z * total + idx];      // loads of 8 slabs in flight
         if (EPI != EPI_NONE) v += to_f32(static_cast<const T*>(a.bias)[n]);
         if (EPI == EPI_BIAS_TANH) v = tanhf(v);
-        static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
+        if (EPI == EPI_NONE && a.csum != nullptr && n == a.Nb) static_cast<T*>(a.csum)[m] = from_f32<T>(v);
+        else static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
     }
 }
 
@@ -221,7 +245,7 @@ int launch_epi(const GemmArgs& a, int epi, dim3 grid, hipStream_t s) {
 
 template <typename T>
 int launch_typed(const GemmDesc& g, GemmArgs& a, hipStream_t s) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, a.splits);
+    dim3 grid((a.N + BN - 1) / BN, (g.M + BM - 1) / BM, a.splits);
     // the split-K main pass writes raw partials; the epilogue runs in the reduce pass
     const int epi_main = a.splits > 1 ? EPI_NONE : g.epilogue;
     int st;
@@ -231,7 +255,7 @@ int launch_typed(const GemmDesc& g, GemmArgs& a, hipStream_t s) {
     else return fail(TVAE_ERR_ARG, "gemm: layout (A k-major, B n-major) is not instantiated");
     TVAE_PROPAGATE(st);
     if (a.splits > 1) {
-        const long long total = (long long)g.M * g.N;
+        const long long total = (long long)a.M * a.N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         switch (g.epilogue) {
@@ -303,7 +327,7 @@ int gemm_launch_pair(const GemmDesc& g0, const GemmDesc& g1, hipStream_t stream)
         long long nb[2];
         const GemmDesc* gs[2] = {&g0, &g1};
         for (int i = 0; i < 2; ++i) {
-            q.gx[i] = (gs[i]->N + BN - 1) / BN;
+            q.gx[i] = (q.p[i].N + BN - 1) / BN;
             q.gy[i] = (gs[i]->M + BM - 1) / BM;
             nb[i] = (long long)q.gx[i] * q.gy[i] * q.p[i].splits;
         }
@@ -323,11 +347,14 @@ int prepare_args(const GemmDesc& g, GemmArgs& a) {
     TVAE_REQUIRE(g.K > 0, "gemm: K must be positive (got %d)", g.K);
     TVAE_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
     TVAE_REQUIRE(g.epilogue == EPI_NONE || g.bias, "gemm: epilogue needs a bias pointer");
+    TVAE_REQUIRE(!g.colsum_out || (g.a_kmajor && g.b_kmajor && g.epilogue == EPI_NONE),
+                 "gemm: a fused column sum needs the weight-gradient layout (A and B k-major, no epilogue)");
     a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.slab = g.slab;
-    a.M = g.M; a.N = g.N; a.K = g.K;
+    a.M = g.M; a.N = g.N + (g.colsum_out ? 1 : 0); a.K = g.K;
+    a.csum = g.colsum_out; a.Nb = g.N;
     a.amap = g.amap; a.bmap = g.bmap; a.cmap = g.cmap;
-    choose_split(g.M, g.N, g.K, &a.splits, &a.k_per_split);
-    if (a.splits > 1 && (!g.slab || g.slab_floats < (int64_t)a.splits * g.M * g.N)) {
+    choose_split(a.M, a.N, g.K, &a.splits, &a.k_per_split);
+    if (a.splits > 1 && (!g.slab || g.slab_floats < (int64_t)a.splits * a.M * a.N)) {
         a.splits = 1;
         a.k_per_split = (g.K + BK - 1) / BK * BK;
     }

@@ -68,7 +68,7 @@ struct TileLds {
 // between one and two phases to land and nothing is ever drained.  Slices and norms are wave-private:
 // the only workgroup barrier per tile is the one of the partial-S' exchange.
 template <int NB, int WAVES, bool GRAD>
-__global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
+__device__ __forceinline__ void mmd_tile_body(const MmdArgs& a, const int block) {
     using L = TileLds<NB, WAVES>;
     constexpr int SW = L::SW, DPAD = WAVES * SW;
     // reduce-scatter exchange: the S' tile is split over the lanes of the workgroup (EPL elements per lane)
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
     const int per_problem = a.row_blocks * a.col_splits;
     // problem 0: rows = z against both column sets (+ gradient when GRAD); problem 1: rows = y against y.
     // The GRAD instantiation is only ever launched for problem 0, so the gradient path is branch-free.
-    const int bid = a.problem_base * per_problem + blockIdx.x;
+    const int bid = a.problem_base * per_problem + block;
     const int problem = GRAD ? 0 : bid / per_problem;
     const int rem = bid - problem * per_problem;
     const int rb = rem / a.col_splits, sp = rem - rb * a.col_splits;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
         }
     }
 #ifdef TVAE_PHASE_TIMING
-    if (blockIdx.x == 0 && lane == 0)
+    if (block == 0 && lane == 0)
         printf("wave %d tiles %d: gram %llu  xch+barrier %llu  E %llu  grad %llu  top %llu (timer ticks per tile)\n", wave,
                te - tb, ph[0] / (te - tb), ph[1] / (te - tb), ph[2] / (te - tb), ph[4] / (te - tb), ph[5] / (te - tb));
 #endif
@@ -469,6 +469,26 @@ __global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_ti
 #pragma unroll
             for (int db = 0; db < NB; ++db) *reinterpret_cast<f32x4*>(grow + 16 * db) = acc[GRAD ? db : 0][t];
         }
+    }
+}
+
+template <int NB, int WAVES, bool GRAD>
+__global__ __launch_bounds__(64 * WAVES, (NB * WAVES <= 48 ? 2 : 1)) void mmd_tile_kernel(MmdArgs a) {
+    mmd_tile_body<NB, WAVES, GRAD>(a, (int)blockIdx.x);
+}
+
+// Single-wave shapes: the gradient problem (z rows against z and y) and the sum-only problem (y rows against y)
+// in ONE launch -- the first nwg0 workgroups take problem 0.  The y-y workgroups are short (symmetric
+// enumeration, no gradient) and fill the tail of the gradient launch instead of a second, poorly filled one
+// (BASELINE cfg2: 12 + 6 us -> one launch; cfg3: the 30 us second launch disappears into the first one's tail).
+template <int NB>
+__global__ __launch_bounds__(64, 2) void mmd_tile_both_kernel(MmdArgs a, int nwg0) {
+    if ((int)blockIdx.x < nwg0) {
+        mmd_tile_body<NB, 1, true>(a, (int)blockIdx.x);
+    } else {
+        MmdArgs b = a;
+        b.problem_base = 1;
+        mmd_tile_body<NB, 1, false>(b, (int)blockIdx.x - nwg0);
     }
 }
 
@@ -750,6 +770,38 @@ int launch_tile(const MmdArgs& a, int nblocks, hipStream_t s) {
     return TVAE_OK;
 }
 
+template <int NB>
+int launch_tile_both(const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
+    constexpr int lds_bytes = TileLds<NB, 1>::BYTES;
+    static std::once_flag once;
+    static hipError_t attr_status = hipSuccess;
+    std::call_once(once, [] {
+        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_tile_both_kernel<NB>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    });
+    TVAE_CHECK_HIP(attr_status);
+    hipLaunchKernelGGL((mmd_tile_both_kernel<NB>), dim3(nwg0 + nwg1), dim3(64), lds_bytes, s, a, nwg0);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+// single-wave shapes only (padded dimension <= 192); returns -1 when there is no such kernel
+int launch_tile_both_shape(int dpad, const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
+    switch (dpad) {
+        case 16: return launch_tile_both<1>(a, nwg0, nwg1, s);
+        case 32: return launch_tile_both<2>(a, nwg0, nwg1, s);
+        case 48: return launch_tile_both<3>(a, nwg0, nwg1, s);
+        case 64: return launch_tile_both<4>(a, nwg0, nwg1, s);
+        case 80: return launch_tile_both<5>(a, nwg0, nwg1, s);
+        case 96: return launch_tile_both<6>(a, nwg0, nwg1, s);
+        case 112: return launch_tile_both<7>(a, nwg0, nwg1, s);
+        case 128: return launch_tile_both<8>(a, nwg0, nwg1, s);
+        case 160: return launch_tile_both<10>(a, nwg0, nwg1, s);
+        case 192: return launch_tile_both<12>(a, nwg0, nwg1, s);
+    }
+    return fail(TVAE_ERR_ARG, "mmd: no single-wave kernel for padded dimension %d", dpad);
+}
+
 template <bool GRAD>
 int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
     switch (dpad) {
@@ -884,7 +936,11 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
-    if (d_z) {
+    if (d_z && !p.bf16_tiles && !p.narrow64 && p.WAVES == 1) {
+        // single-wave shapes: both problems in one launch (row blocks are the same 32 rows in both)
+        a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks;
+        TVAE_PROPAGATE(launch_tile_both_shape(p.DPAD, a, nwg0, nwg1, s));
+    } else if (d_z) {
         a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks_g;
         TVAE_PROPAGATE(launch_tiles<true>(p, a, nwg0, s));              // z rows: sums + gradient
         a.problem_base = 1; a.sums_base = nwg0; a.row_blocks = p.row_blocks;

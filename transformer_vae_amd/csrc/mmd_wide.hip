@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void wide_final_kernel(const double* __restric
 
 int strip_gemm(const float* A, long long lda, const float* B, long long ldb, bool b_kmajor, float* C, long long ldc,
                int M, int N, int K, float* slab, int64_t slab_floats, hipStream_t s) {
-    GemmDesc g;
+    GemmDesc g{};
     g.A = A; g.B = B; g.C = C; g.bias = nullptr;
     g.M = M; g.N = N; g.K = K;
     g.a_kmajor = false; g.b_kmajor = b_kmajor;

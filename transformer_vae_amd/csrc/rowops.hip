@@ -167,6 +167,88 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_vec_kernel(const T* __restric
     }
 }
 
+// LayerNorm backward with the parameter gradients folded in: the wave that turns row r of dout into dr also holds
+// dout * xhat and dout of that row, so it accumulates them per column over its `rows_per_wave` consecutive rows, the
+// four waves of a workgroup add their sums through LDS in a fixed order (deterministic), and ONE partial per
+// workgroup goes out for col_final_pair_kernel.  Replaces a second pass over dout and the pre-norm activations
+// (col_partial_kernel<T, 1>) and one of the two final launches.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_fused_vec_kernel(const T* __restrict__ dout, const T* __restrict__ r,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const T* __restrict__ gamma, T* __restrict__ dr,
+                                                               long long rows, int d, int rows_per_wave,
+                                                               float* __restrict__ part_g, float* __restrict__ part_b) {
+    extern __shared__ float ln_sm[];      // [ROWS_PER_BLOCK][2][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ng = d >> 2;
+    const long long row0 = ((long long)blockIdx.x * ROWS_PER_BLOCK + wave) * rows_per_wave;
+    const long long row1 = min(rows, row0 + (long long)rows_per_wave);
+    float ag[LN_MAXG][4], ab[LN_MAXG][4];
+#pragma unroll
+    for (int k = 0; k < LN_MAXG; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+    }
+    for (long long row = row0; row < row1; ++row) {
+        const T* g = dout + row * d;
+        const T* x = r + row * d;
+        const float mu = mean[row], rs = rstd[row];
+        float dxh[LN_MAXG][4], xh[LN_MAXG][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXG; ++k) {
+            const int gidx = lane + 64 * k;
+            if (gidx < ng) {
+                float gv[4], gm[4];
+                load4_vec(g + 4 * gidx, gv);
+                load4_vec(gamma + 4 * gidx, gm);      // (L1/L2-resident; in the loop so that it flies with the row)
+                load4_vec(x + 4 * gidx, xh[k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dxh[k][e] = gv[e] * gm[e];
+                    xh[k][e] = (xh[k][e] - mu) * rs;
+                    s1 += dxh[k][e];
+                    s2 = fmaf(dxh[k][e], xh[k][e], s2);
+                    ag[k][e] = fmaf(gv[e], xh[k][e], ag[k][e]);
+                    ab[k][e] += gv[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+        T* o = dr + row * d;
+#pragma unroll
+        for (int k = 0; k < LN_MAXG; ++k) {
+            const int gidx = lane + 64 * k;
+            if (gidx < ng) {
+                float w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = rs * (dxh[k][e] - s1 - xh[k][e] * s2);
+                store4_vec(o + 4 * gidx, w);
+            }
+        }
+    }
+    // workgroup sum: every wave parks its column sums in LDS (a wave without rows parks zeros), one barrier,
+    // then the four are added in wave order
+    float* mine = ln_sm + (size_t)wave * 2 * d;
+#pragma unroll
+    for (int k = 0; k < LN_MAXG; ++k) {
+        const int gidx = lane + 64 * k;
+        if (gidx < ng) {
+            *reinterpret_cast<float4*>(mine + 4 * gidx) = make_float4(ag[k][0], ag[k][1], ag[k][2], ag[k][3]);
+            *reinterpret_cast<float4*>(mine + d + 4 * gidx) = make_float4(ab[k][0], ab[k][1], ab[k][2], ab[k][3]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        float v = ln_sm[c];
+#pragma unroll
+        for (int w = 1; w < ROWS_PER_BLOCK; ++w) v += ln_sm[(size_t)w * 2 * d + c];
+        if (c < d) part_g[(long long)blockIdx.x * d + c] = v;
+        else part_b[(long long)blockIdx.x * d + (c - d)] = v;
+    }
+}
+
 inline bool ln_vec_ok(int64_t d, int dtype, const void* a, const void* b, const void* c, const void* e) {
     const uintptr_t align = dtype == TVAE_F32 ? 16 : 8;
     auto ok = [&](const void* p) { return p == nullptr || reinterpret_cast<uintptr_t>(p) % align == 0; };
@@ -228,6 +310,30 @@ __global__ __launch_bounds__(1024) void col_final_kernel(const float* __restrict
     }
 }
 
+// the two column sums of a LayerNorm backward (gamma: blockIdx.y = 0, beta: 1) in one launch
+template <typename T>
+__global__ __launch_bounds__(1024) void col_final_pair_kernel(const float* __restrict__ part0, const float* __restrict__ part1,
+                                                              int chunks, int cols, T* __restrict__ out0, T* __restrict__ out1) {
+    __shared__ double red[16][64];
+    const float* __restrict__ part = blockIdx.y ? part1 : part0;
+    T* __restrict__ out = blockIdx.y ? out1 : out0;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s = 0.0;
+    if (c < cols) {
+#pragma unroll 8
+        for (int k = ry; k < chunks; k += 16) s += (double)part[(long long)k * cols + c];
+    }
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        out[c] = from_f32<T>((float)t);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                        T* __restrict__ dpre, long long count) {
@@ -260,6 +366,58 @@ __global__ __launch_bounds__(256) void zero_tail_kernel(char* __restrict__ dh, l
 inline int row_blocks(int64_t rows) { return (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
 inline int col_chunks(int64_t rows) { return (int)((rows + COL_CHUNK_ROWS - 1) / COL_CHUNK_ROWS); }
 
+// rows per wave of the fused LayerNorm backward: one at the reference's batch sizes (latency-bound: as many waves
+// as rows), more once there are enough rows to fill the chip, so that the partials stay small next to the input
+inline int ln_fused_rows_per_wave(int64_t rows) {
+    const int64_t r = (rows + 4095) / 4096;
+    return (int)(r < 1 ? 1 : r);
+}
+inline int ln_fused_blocks(int64_t rows) {
+    const int64_t per_block = (int64_t)ROWS_PER_BLOCK * ln_fused_rows_per_wave(rows);
+    return (int)((rows + per_block - 1) / per_block);
+}
+
+}  // namespace
+
+int64_t layernorm_bwd_scratch_floats(int64_t rows, int64_t d) {
+    const int64_t fused = 2 * (int64_t)ln_fused_blocks(rows) * d;
+    const int64_t plain = 2 * (int64_t)col_chunks(rows) * d;
+    return fused > plain ? fused : plain;
+}
+
+// dr and (dgamma, dbeta) in one pass over dout and the pre-norm activations + one final launch; returns
+// TVAE_ERR_ARG (without a message change) when the shape needs the separate kernels -- callers test
+// layernorm_bwd_can_fuse first.
+bool layernorm_bwd_can_fuse(const void* dout, const void* r, const void* gamma, const void* dr, int64_t d, int dtype) {
+    return ln_vec_ok(d, dtype, dout, r, gamma, dr) && ROWS_PER_BLOCK * 2 * d * 4 <= 64 * 1024;
+}
+
+int layernorm_bwd_fused(const void* dout, const void* r, const float* mean, const float* rstd, const void* gamma,
+                        void* dr, void* dgamma, void* dbeta, int64_t rows, int64_t d, int dtype, float* scratch,
+                        hipStream_t s) {
+    TVAE_REQUIRE(rows > 0 && d > 0, "layernorm_bwd_fused: empty input");
+    TVAE_REQUIRE(layernorm_bwd_can_fuse(dout, r, gamma, dr, d, dtype), "layernorm_bwd_fused: shape not supported");
+    const int rpw = ln_fused_rows_per_wave(rows), blocks = ln_fused_blocks(rows);
+    float* p0 = scratch;
+    float* p1 = scratch + (int64_t)blocks * d;
+    const size_t lds = (size_t)ROWS_PER_BLOCK * 2 * d * 4;
+    const dim3 fgrid((unsigned)((d + 63) / 64), 2);
+    if (dtype == TVAE_F32) {
+        hipLaunchKernelGGL(ln_bwd_fused_vec_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)dout,
+                           (const float*)r, mean, rstd, (const float*)gamma, (float*)dr, (long long)rows, (int)d, rpw, p0, p1);
+        hipLaunchKernelGGL(col_final_pair_kernel<float>, fgrid, dim3(1024), 0, s, p0, p1, blocks, (int)d, (float*)dgamma,
+                           (float*)dbeta);
+    } else {
+        hipLaunchKernelGGL(ln_bwd_fused_vec_kernel<bf16>, dim3(blocks), dim3(256), lds, s, (const bf16*)dout,
+                           (const bf16*)r, mean, rstd, (const bf16*)gamma, (bf16*)dr, (long long)rows, (int)d, rpw, p0, p1);
+        hipLaunchKernelGGL(col_final_pair_kernel<bf16>, fgrid, dim3(1024), 0, s, p0, p1, blocks, (int)d, (bf16*)dgamma,
+                           (bf16*)dbeta);
+    }
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+namespace {
 }  // namespace
 
 int layernorm_fwd(const void* r, const void* gamma, const void* beta, float eps, void* out, float* mean, float* rstd,

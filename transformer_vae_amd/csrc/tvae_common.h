@@ -104,6 +104,10 @@ struct GemmDesc {
     int epilogue;
     int dtype;
     float* slab; int64_t slab_floats;   // split-K scratch (fp32), may be null => no split
+    // weight-gradient layout only (A and B k-major, no epilogue), nullable: colsum_out[m] = sum_k A(m,k), i.e. the
+    // bias gradient, computed by the same launch through a virtual column of ones appended to B (size the slabs
+    // with N + 1 columns)
+    void* colsum_out;
 };
 int64_t gemm_slab_floats(int M, int N, int K);
 int gemm_launch(const GemmDesc& g, hipStream_t stream);
@@ -121,6 +125,13 @@ int colsum(const void* x, int64_t rows, int64_t cols, void* out, int dtype, floa
 int layernorm_bwd_params(const void* dout, const void* r, const float* mean, const float* rstd,
                          void* dgamma, void* dbeta, int64_t rows, int64_t d, int dtype,
                          float* scratch /* 2x colreduce_scratch_floats */, hipStream_t s);
+// input gradient and (dgamma, dbeta) in one pass + one final launch (register-resident rows: d % 4 == 0,
+// d <= 2048, aligned); scratch = layernorm_bwd_scratch_floats(rows, d) fp32 (covers layernorm_bwd_params too)
+int64_t layernorm_bwd_scratch_floats(int64_t rows, int64_t d);
+bool layernorm_bwd_can_fuse(const void* dout, const void* r, const void* gamma, const void* dr, int64_t d, int dtype);
+int layernorm_bwd_fused(const void* dout, const void* r, const float* mean, const float* rstd, const void* gamma,
+                        void* dr, void* dgamma, void* dbeta, int64_t rows, int64_t d, int dtype, float* scratch,
+                        hipStream_t s);
 int tanh_bwd(const void* dz, const void* z, void* dpre, int64_t count, int dtype, hipStream_t s);
 int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype, hipStream_t s);
 
