@@ -18,7 +18,28 @@
 namespace tvae {
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = 65;
+// (the TVAE_* macros below exist for A/B builds of single constants: tools/build_variant.sh)
+#ifndef TVAE_BK
+#define TVAE_BK 32
+#endif
+#ifndef TVAE_SPLIT_TARGET
+#define TVAE_SPLIT_TARGET 2048
+#endif
+#ifndef TVAE_PAIR_MAX
+#define TVAE_PAIR_MAX 4096
+#endif
+#ifdef TVAE_GEMM_MINWAVES
+#define TVAE_GEMM_BOUNDS __launch_bounds__(256, TVAE_GEMM_MINWAVES)
+#else
+#define TVAE_GEMM_BOUNDS __launch_bounds__(256)
+#endif
+constexpr int BM = 64, BN = 64, BK = TVAE_BK, LDS_LD = 65;
+// Latency-bound launches (few workgroups, short K per workgroup -- every product of the reference's own batch
+// sizes) walk K in 96-deep tiles instead: a cold global load costs ~2 us and the K loop pays it once per tile,
+// so K = 77 (the default latent size) is ONE load phase instead of three, and a 768-deep product split eight
+// ways is one phase per workgroup.  2 x 96 x 65 floats = 49.9 KB of LDS, three workgroups per CU.
+constexpr int BK_DEEP = 96;
+constexpr int DEEP_MAX_BLOCKS = 512;       // use the deep tiles when the whole launch is at most this many workgroups (measured: at 1 000-2 600 workgroups, BASELINE cfg3, they are 15-30 % slower than the 32-deep ones)
 
 struct GemmArgs {
     const void* A; const void* B; void* C; const void* bias; float* slab;
@@ -28,20 +49,23 @@ struct GemmArgs {
     // weight-gradient products only (A and B k-major): B gets a virtual column of ones at index Nb (= N - 1), so
     // that output column Nb is the column sum of A over k = the bias gradient, written to csum[m] instead of C
     void* csum; int Nb;
+    int deep;      // 1: BK_DEEP-deep K tiles (small launches)
 };
 
-// A (64 rows x 32 k) operand tile travels global -> registers -> LDS (as tile[k][row]) in two halves,
-// so that the global loads of tile t+1 are in flight while tile t is multiplied.
-template <typename T, bool KMAJOR>
-__device__ __forceinline__ void tile_load(float v[2][4], const T* __restrict__ P, const RowMap& map, int r0, int R,
+// A (64 rows x BKT k) operand tile travels global -> registers -> LDS (as tile[k][row]) in BKT/16 pieces per
+// thread, so that the global loads of tile t+1 are in flight while tile t is multiplied.
+// (Measured and not kept: a branch-free form -- out-of-range chunks read element 0 and are zeroed by selects, so
+// that no load sits behind a bounds check -- was 0-20 % SLOWER at the BASELINE cfg2/cfg3 shapes.)
+template <typename T, bool KMAJOR, int BKT>
+__device__ __forceinline__ void tile_load(float v[BKT / 16][4], const T* __restrict__ P, const RowMap& map, int r0, int R,
                                           int k0, int kend, bool vec, int tid) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < BKT / 16; ++j) {
         const int q = tid + 256 * j;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[j][e] = 0.f;
         if (!KMAJOR) {
-            const int row = q >> 3, kq = (q & 7) * 4;
+            const int row = q / (BKT / 4), kq = (q % (BKT / 4)) * 4;
             const int r = r0 + row, k = k0 + kq;
             if (r < R && k < kend) {
                 const T* p = P + map(r) + k;
@@ -61,9 +85,10 @@ __device__ __forceinline__ void tile_load(float v[2][4], const T* __restrict__ P
 }
 
 // the virtual ones column of a k-major B tile (see GemmArgs::csum): element (k, Nb) = 1 for k < kend
-__device__ __forceinline__ void tile_ones(float v[2][4], int r0, int Nb, int k0, int kend, int tid) {
+template <int BKT>
+__device__ __forceinline__ void tile_ones(float v[BKT / 16][4], int r0, int Nb, int k0, int kend, int tid) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < BKT / 16; ++j) {
         const int q = tid + 256 * j;
         const int krow = q >> 4, rq = (q & 15) * 4;
         const int e = Nb - (r0 + rq);
@@ -74,13 +99,13 @@ __device__ __forceinline__ void tile_ones(float v[2][4], int r0, int Nb, int k0,
     }
 }
 
-template <bool KMAJOR>
-__device__ __forceinline__ void tile_store(float (*tile)[LDS_LD], const float v[2][4], int tid) {
+template <bool KMAJOR, int BKT>
+__device__ __forceinline__ void tile_store(float (*tile)[LDS_LD], const float v[BKT / 16][4], int tid) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < BKT / 16; ++j) {
         const int q = tid + 256 * j;
         if (!KMAJOR) {
-            const int row = q >> 3, kq = (q & 7) * 4;
+            const int row = q / (BKT / 4), kq = (q % (BKT / 4)) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) tile[kq + e][row] = v[j][e];
         } else {
@@ -91,7 +116,7 @@ __device__ __forceinline__ void tile_store(float (*tile)[LDS_LD], const float v[
     }
 }
 
-template <typename T, bool A_KMAJOR, bool B_KMAJOR, int EPI>
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, int EPI, int BKT>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by, int bz, float (*As)[LDS_LD],
                                                float (*Bs)[LDS_LD]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,21 +135,21 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by
     constexpr bool CSUM = A_KMAJOR && B_KMAJOR && EPI == EPI_NONE;   // the weight-gradient instantiation
     const bool csum = CSUM && a.csum != nullptr;
     const int nb_real = csum ? a.Nb : a.N;                            // columns B really has
-    float ra[2][4], rb[2][4];
-    tile_load<T, A_KMAJOR>(ra, A, a.amap, m0, a.M, kbeg, kend, a.vecA, tid);
-    tile_load<T, B_KMAJOR>(rb, B, a.bmap, n0, nb_real, kbeg, kend, a.vecB, tid);
-    if (CSUM && csum) tile_ones(rb, n0, a.Nb, kbeg, kend, tid);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        tile_store<A_KMAJOR>(As, ra, tid);
-        tile_store<B_KMAJOR>(Bs, rb, tid);
+    float ra[BKT / 16][4], rb[BKT / 16][4];
+    tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, kbeg, kend, a.vecA, tid);
+    tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, kbeg, kend, a.vecB, tid);
+    if (CSUM && csum) tile_ones<BKT>(rb, n0, a.Nb, kbeg, kend, tid);
+    for (int k0 = kbeg; k0 < kend; k0 += BKT) {
+        tile_store<A_KMAJOR, BKT>(As, ra, tid);
+        tile_store<B_KMAJOR, BKT>(Bs, rb, tid);
         __syncthreads();
-        if (k0 + BK < kend) {      // next tile's loads fly during this tile's MFMAs
-            tile_load<T, A_KMAJOR>(ra, A, a.amap, m0, a.M, k0 + BK, kend, a.vecA, tid);
-            tile_load<T, B_KMAJOR>(rb, B, a.bmap, n0, nb_real, k0 + BK, kend, a.vecB, tid);
-            if (CSUM && csum) tile_ones(rb, n0, a.Nb, k0 + BK, kend, tid);
+        if (k0 + BKT < kend) {      // next tile's loads fly during this tile's MFMAs
+            tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, k0 + BKT, kend, a.vecA, tid);
+            tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, k0 + BKT, kend, a.vecB, tid);
+            if (CSUM && csum) tile_ones<BKT>(rb, n0, a.Nb, k0 + BKT, kend, tid);
         }
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
+        for (int s = 0; s < BKT / 2; ++s) {
             const float av = As[2 * s + h][wr * 32 + i32];
             const float bv = Bs[2 * s + h][wc * 32 + i32];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
@@ -153,11 +178,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by
     }
 }
 
-template <typename T, bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs a) {
-    __shared__ float As[BK][LDS_LD];
-    __shared__ float Bs[BK][LDS_LD];
-    gemm_tile_body<T, A_KMAJOR, B_KMAJOR, EPI>(a, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+template <typename T, bool A_KMAJOR, bool B_KMAJOR, int EPI, int BKT>
+__global__ TVAE_GEMM_BOUNDS void gemm_f32_mfma_kernel(GemmArgs a) {
+    __shared__ float As[BKT][LDS_LD];
+    __shared__ float Bs[BKT][LDS_LD];
+    gemm_tile_body<T, A_KMAJOR, B_KMAJOR, EPI, BKT>(a, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 
 // Two independent products in ONE launch (the two backward products of a projection: the activation gradient
@@ -168,18 +193,18 @@ struct GemmPairArgs {
     int gx[2], gy[2], nblk0;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPairArgs q) {
-    __shared__ float As[BK][LDS_LD];
-    __shared__ float Bs[BK][LDS_LD];
+template <typename T, int BKT>
+__global__ TVAE_GEMM_BOUNDS void gemm_pair_kernel(GemmPairArgs q) {
+    __shared__ float As[BKT][LDS_LD];
+    __shared__ float Bs[BKT][LDS_LD];
     int b = blockIdx.x;
     if (b < q.nblk0) {
         const int bx = b % q.gx[0], t = b / q.gx[0];
-        gemm_tile_body<T, false, true, EPI_NONE>(q.p[0], bx, t % q.gy[0], t / q.gy[0], As, Bs);
+        gemm_tile_body<T, false, true, EPI_NONE, BKT>(q.p[0], bx, t % q.gy[0], t / q.gy[0], As, Bs);
     } else {
         b -= q.nblk0;
         const int bx = b % q.gx[1], t = b / q.gx[1];
-        gemm_tile_body<T, true, true, EPI_NONE>(q.p[1], bx, t % q.gy[1], t / q.gy[1], As, Bs);
+        gemm_tile_body<T, true, true, EPI_NONE, BKT>(q.p[1], bx, t % q.gy[1], t / q.gy[1], As, Bs);
     }
 }
 
@@ -212,35 +237,61 @@ __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(GemmPairArgs q) {
                                         (long long)(gridDim.x - q.nblk0) * 256);
 }
 
-void choose_split(int M, int N, int K, int* splits, int* k_per_split) {
+// split count and K range per split for K tiles of depth `bk`
+void choose_split_bk(int M, int N, int K, int bk, int* splits, int* k_per_split) {
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int s = 1;
-    if (tiles < 256 && K > 256) {
+    if (tiles < 256 && K > (bk == BK ? 256 : bk)) {
         // enough workgroups for ~8 per CU: with one 32x32 accumulator per wave the kernel hides its global
         // loads through occupancy (2-3 workgroups per CU left the weight-gradient products at 30 % MFMA-busy)
-        s = (int)((2048 + tiles - 1) / tiles);
-        const int max_s = (K + 127) / 128;
+        s = (int)((TVAE_SPLIT_TARGET + tiles - 1) / tiles);
+        const int max_s = bk == BK ? (K + 127) / 128 : (K + bk - 1) / bk;
         if (s > max_s) s = max_s;
         if (s > 64) s = 64;
         if (s < 1) s = 1;
     }
     int kps = (K + s - 1) / s;
-    kps = (kps + BK - 1) / BK * BK;
-    if (kps < BK) kps = BK;
+    kps = (kps + bk - 1) / bk * bk;
+    if (kps < bk) kps = bk;
     *k_per_split = kps;
     *splits = (K + kps - 1) / kps;
     if (*splits < 1) *splits = 1;
 }
 
-template <typename T, bool AK, bool BKM>
-int launch_epi(const GemmArgs& a, int epi, dim3 grid, hipStream_t s) {
+int deep_max_blocks() {
+#ifdef TVAE_TUNING
+    static const int v = getenv("TVAE_GEMM_DEEP_MAX_BLOCKS") ? atoi(getenv("TVAE_GEMM_DEEP_MAX_BLOCKS")) : DEEP_MAX_BLOCKS;
+    return v;
+#else
+    return DEEP_MAX_BLOCKS;
+#endif
+}
+
+// Small launches take the deep K tiles (and split K down to one tile per workgroup); everything else the 32-deep ones.
+void choose_split(int M, int N, int K, int* splits, int* k_per_split, int* deep) {
+    const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    choose_split_bk(M, N, K, BK_DEEP, splits, k_per_split);
+    *deep = 1;
+    if (tiles * *splits > deep_max_blocks()) {
+        choose_split_bk(M, N, K, BK, splits, k_per_split);
+        *deep = 0;
+    }
+}
+
+template <typename T, bool AK, bool BKM, int BKT>
+int launch_epi_bk(const GemmArgs& a, int epi, dim3 grid, hipStream_t s) {
     switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_NONE>), grid, dim3(256), 0, s, a); break;
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_BIAS>), grid, dim3(256), 0, s, a); break;
-        case EPI_BIAS_TANH: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_BIAS_TANH>), grid, dim3(256), 0, s, a); break;
+        case EPI_NONE: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_NONE, BKT>), grid, dim3(256), 0, s, a); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_BIAS, BKT>), grid, dim3(256), 0, s, a); break;
+        case EPI_BIAS_TANH: hipLaunchKernelGGL((gemm_f32_mfma_kernel<T, AK, BKM, EPI_BIAS_TANH, BKT>), grid, dim3(256), 0, s, a); break;
         default: return fail(TVAE_ERR_ARG, "gemm: bad epilogue %d", epi);
     }
     return TVAE_OK;
+}
+
+template <typename T, bool AK, bool BKM>
+int launch_epi(const GemmArgs& a, int epi, dim3 grid, hipStream_t s) {
+    return a.deep ? launch_epi_bk<T, AK, BKM, BK_DEEP>(a, epi, grid, s) : launch_epi_bk<T, AK, BKM, BK>(a, epi, grid, s);
 }
 
 template <typename T>
@@ -271,8 +322,8 @@ int launch_typed(const GemmDesc& g, GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int64_t gemm_slab_floats(int M, int N, int K) {
-    int s, kps;
-    choose_split(M, N, K, &s, &kps);
+    int s, kps, deep;
+    choose_split(M, N, K, &s, &kps, &deep);
     return s > 1 ? (int64_t)s * M * N : 0;
 }
 
@@ -292,7 +343,8 @@ int gemm_launch(const GemmDesc& g, hipStream_t stream) {
 namespace {
 template <typename T>
 int launch_pair_typed(const GemmPairArgs& q, int nblk, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_pair_kernel<T>), dim3(nblk), dim3(256), 0, s, q);
+    if (q.p[0].deep) hipLaunchKernelGGL((gemm_pair_kernel<T, BK_DEEP>), dim3(nblk), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((gemm_pair_kernel<T, BK>), dim3(nblk), dim3(256), 0, s, q);
     const GemmArgs& a0 = q.p[0];
     const GemmArgs& a1 = q.p[1];
     auto rblocks = [](const GemmArgs& a) {
@@ -331,7 +383,7 @@ int gemm_launch_pair(const GemmDesc& g0, const GemmDesc& g1, hipStream_t stream)
             q.gy[i] = (gs[i]->M + BM - 1) / BM;
             nb[i] = (long long)q.gx[i] * q.gy[i] * q.p[i].splits;
         }
-        if (nb[0] + nb[1] <= 4096) {
+        if (nb[0] + nb[1] <= TVAE_PAIR_MAX && q.p[0].deep == q.p[1].deep) {      // (one K-tile depth per launch)
             q.nblk0 = (int)nb[0];
             if (g0.dtype == TVAE_F32) return launch_pair_typed<float>(q, (int)(nb[0] + nb[1]), stream);
             if (g0.dtype == TVAE_BF16) return launch_pair_typed<bf16>(q, (int)(nb[0] + nb[1]), stream);
@@ -353,9 +405,10 @@ int prepare_args(const GemmDesc& g, GemmArgs& a) {
     a.M = g.M; a.N = g.N + (g.colsum_out ? 1 : 0); a.K = g.K;
     a.csum = g.colsum_out; a.Nb = g.N;
     a.amap = g.amap; a.bmap = g.bmap; a.cmap = g.cmap;
-    choose_split(a.M, a.N, g.K, &a.splits, &a.k_per_split);
+    choose_split(a.M, a.N, g.K, &a.splits, &a.k_per_split, &a.deep);
     if (a.splits > 1 && (!g.slab || g.slab_floats < (int64_t)a.splits * a.M * a.N)) {
         a.splits = 1;
+        a.deep = 0;
         a.k_per_split = (g.K + BK - 1) / BK * BK;
     }
     const size_t align = g.dtype == TVAE_F32 ? 16 : 8;
