@@ -517,20 +517,58 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
     if (wg < nw0) { r0 = wg * rows_per_wave; r1 = min(lo, r0 + rows_per_wave); }
     else if (wg < nw0 + nw1) { r0 = lo + (wg - nw0) * rows_per_wave; r1 = min(hi, r0 + rows_per_wave); }
     else { r0 = hi + (wg - nw0 - nw1) * rows_per_wave; r1 = min(n_pad, r0 + rows_per_wave); }
-    for (int row = r0; row < r1; ++row) {
-        float sq = 0.f;
+    if (NJ <= 4) {
+        // narrow rows (DPAD <= 256) carry one to four loads per lane: four rows at a time, every load issued before
+        // the first use (out-of-range elements read src[0] and are zeroed by a select), so a wave pays one memory
+        // latency per four rows instead of one per row (BASELINE cfg3, ten rows per wave: 15 -> 7 us)
+        for (int row = r0; row < r1; row += 4) {
+            float v[4][4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int c = lane + 64 * j;
-            if (j < NJ && c < DPAD) {
-                const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
-                dst[(long long)row * DPAD + c] = from_f32<TC>(v);    // TC == bf16 only with T == bf16: exact
-                csum[j] += v;
-                sq = fmaf(v, v, sq);
+            for (int u = 0; u < 4; ++u) {
+                const int rr = row + u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = lane + 64 * j;
+                    const bool ok = j < NJ && c < D && rr < r1 && rr < n_total;
+                    const float t = to_f32(src[ok ? (long long)rr * D + c : 0ll]);
+                    v[u][j] = ok ? t : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = row + u;
+                if (rr < r1) {
+                    float sq = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = lane + 64 * j;
+                        if (j < NJ && c < DPAD) {
+                            dst[(long long)rr * DPAD + c] = from_f32<TC>(v[u][j]);
+                            csum[j] += v[u][j];
+                            sq = fmaf(v[u][j], v[u][j], sq);
+                        }
+                    }
+                    sq = wave_sum(sq);
+                    if (lane == 0) nrm[rr] = sq;
+                }
             }
         }
-        sq = wave_sum(sq);
-        if (lane == 0) nrm[row] = sq;
+    } else {
+        for (int row = r0; row < r1; ++row) {
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = lane + 64 * j;
+                if (j < NJ && c < DPAD) {
+                    const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
+                    dst[(long long)row * DPAD + c] = from_f32<TC>(v);    // TC == bf16 only with T == bf16: exact
+                    csum[j] += v;
+                    sq = fmaf(v, v, sq);
+                }
+            }
+            sq = wave_sum(sq);
+            if (lane == 0) nrm[row] = sq;
+        }
     }
     float* cp = colpart + ((long long)set * nwaves + wg) * DPAD;
 #pragma unroll
@@ -596,10 +634,12 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
         double zz = 0.0, zy = 0.0, yy = 0.0;
+#pragma unroll 4
         for (int w = tid; w < f.nwg0; w += 256) {
             zz += f.wg_sums[2 * (long long)w + 0];
             zy += f.wg_sums[2 * (long long)w + 1];
         }
+#pragma unroll 4
         for (int w = tid; w < f.nwg1; w += 256) yy += f.wg_sums[2 * ((long long)f.nwg0 + w) + 1];
         red[0][tid] = zz; red[1][tid] = zy; red[2][tid] = yy;
         __syncthreads();
@@ -615,6 +655,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
         __syncthreads();
         // linear part in closed form:  sum_{i local, j} |a_i - b_j|^2 = N A_loc + n_loc A_all - 2 <c_loc, c_all>
         double az = 0.0, ay = 0.0, azl = 0.0, ayl = 0.0;
+#pragma unroll 4
         for (int i = tid; i < f.n_total; i += 256) {
             const double vz = (double)f.zn[i], vy = (double)f.yn[i];
             az += vz; ay += vy;
@@ -648,7 +689,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
         const int row = (int)(idx / f.D), c = (int)(idx - (long long)row * f.D);
         double rsum = 0.0;
         float gsum = 0.f;
-#pragma unroll 4
+#pragma unroll 8
         for (int s = 0; s < f.col_splits; ++s) {
             rsum += f.wg_rowsum[(long long)s * f.n_rows_pad + row];
             gsum += f.wg_grad[((long long)s * f.n_rows_pad + row) * f.DPAD + c];
