@@ -75,6 +75,20 @@ int tvae_encode_bwd(const void* d_latent, const void* latent,
                     int64_t B, int64_t S, int64_t n_eff, int64_t d, int64_t L,
                     int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* tvae_encode_bwd with the latent cotangent given in two parts (saves the caller a pass to add them):
+ *     cotangent of `latent` = d_latent + (*extra_scale) * d_latent_extra
+ * In the model this is the decoder's share plus the regulariser's: the gradient of `loss = ce + reg * w`
+ * (transformer_vae/model.py:305-306) reaches the latent through both, and the regulariser's gradient is
+ * saved unscaled by tvae_mmd_fwd_bwd while its upstream factor (w times whatever the trainer applies,
+ * trainer.py:258-281) only exists as a device scalar during backward.
+ *   d_latent_extra (B, n_eff, L) in `dtype`;  extra_scale: DEVICE pointer to one float.
+ * Workspace: tvae_encode_bwd_workspace_bytes. */
+int tvae_encode_bwd_sum(const void* d_latent, const void* d_latent_extra, const float* extra_scale,
+                        const void* latent, const void* h, int64_t h_stride_b, int64_t h_stride_s,
+                        const void* We, void* dh, void* dWe, void* dbe,
+                        int64_t B, int64_t S, int64_t n_eff, int64_t d, int64_t L,
+                        int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Latent decoder.  Replaces LatentDecoderNTokens.forward (autoencoders.py:38-39) and,
  * when gamma != NULL, LatentDecoderFunnelNorm.forward (autoencoders.py:66-67):

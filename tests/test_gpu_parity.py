@@ -872,6 +872,28 @@ def test_fused_step_equals_the_three_separate_nodes(B, S, d, n, L, dec, dtype):
     assert res[2][3]["h"] is None and res[2][3]["encoder.token_to_latent.bias"] is None
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_summed_latent_cotangent_entry_point(dtype):
+    """The usual training loss (reconstruction term + w * reg_loss, nothing on `latent` itself) takes
+    tvae_encode_bwd_sum in the one-node path: the decoder's and the regulariser's shares are added inside the
+    tanh-backward pass.  Same gradients as the three-node path, which adds them with torch, to one rounding."""
+    B, S, d, n, L = 70, 30, 768, 5, 77
+    h, params, prior, g0 = orc.synth_inputs(B, S, d, n, L, 12, "")
+    res = []
+    for fuse in (True, False):
+        vae = build_vae(d, L, n, "", params, dtype, 1e-9)
+        vae.fuse_step = fuse
+        ht = torch.from_numpy(h).to(dev()).to(dtype).requires_grad_(True)
+        out = vae(input_encoding=ht, true_samples=torch.from_numpy(prior).to(dev()))
+        (out.reg_loss * 0.37 + (out.reconstructed_encoding.float() * torch.from_numpy(g0).to(dev())).sum()).backward()
+        grads = {k: p.grad.float().cpu().numpy() for k, p in vae.named_parameters()}
+        grads["h"] = ht.grad.float().cpu().numpy()
+        res.append(grads)
+    tol = 1e-6 if dtype == torch.float32 else BF16_TOL
+    for k in res[0]:
+        assert relerr(res[0][k], res[1][k]) <= tol, k
+
+
 def test_fused_step_is_bypassed_when_it_must_be():
     """Hooks on the sub-modules, autocast, a given latent, skip_reg_loss and the t5_norm / identity decoders keep
     the separate nodes (the fused node would hide them)."""

@@ -30,6 +30,8 @@ SIGNATURES = {
     "tvae_encode_bwd_workspace_bytes": (_i64, [_i64] * 4),
     "tvae_encode_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int,
                                _vp, _i64, _vp]),
+    "tvae_encode_bwd_sum": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                   _int, _vp, _i64, _vp]),
     "tvae_decode_fwd_workspace_bytes": (_i64, [_i64] * 3),
     "tvae_decode_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _i64,
                                _vp]),

@@ -100,10 +100,12 @@ extern "C" int64_t tvae_encode_bwd_workspace_bytes(int64_t B, int64_t n_eff, int
     return s.off;
 }
 
-extern "C" int tvae_encode_bwd(const void* d_latent, const void* latent, const void* h, int64_t h_stride_b,
-                               int64_t h_stride_s, const void* We, void* dh, void* dWe, void* dbe, int64_t B,
-                               int64_t S, int64_t n_eff, int64_t d, int64_t L, int dtype, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+namespace {
+// d_latent_extra / extra_scale: nullable pair; the latent cotangent is d_latent + *extra_scale * d_latent_extra
+int encode_bwd_impl(const void* d_latent, const void* d_latent_extra, const float* extra_scale, const void* latent,
+                    const void* h, int64_t h_stride_b, int64_t h_stride_s, const void* We, void* dh, void* dWe, void* dbe,
+                    int64_t B, int64_t S, int64_t n_eff, int64_t d, int64_t L, int dtype, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     TVAE_REQUIRE(dtype_ok(dtype), "encode_bwd: unknown dtype %d", dtype);
     TVAE_REQUIRE(d_latent && latent && We, "encode_bwd: null pointer argument");
@@ -122,7 +124,8 @@ extern "C" int tvae_encode_bwd(const void* d_latent, const void* latent, const v
         return fail(TVAE_ERR_WORKSPACE, "encode_bwd: workspace %lld B < required %lld B", (long long)workspace_bytes,
                     (long long)ar.off);
 
-    TVAE_PROPAGATE(tanh_bwd(d_latent, latent, dpre, rows * L, dtype, s));
+    if (d_latent_extra) TVAE_PROPAGATE(tanh_bwd_sum(d_latent, d_latent_extra, extra_scale, latent, dpre, rows * L, dtype, s));
+    else TVAE_PROPAGATE(tanh_bwd(d_latent, latent, dpre, rows * L, dtype, s));
     GemmDesc gh{}, gw{};
     if (dh) {
         // rows >= n_eff of every sequence: exact zeros (slice backward); rows < n_eff: d_pre @ We
@@ -149,6 +152,25 @@ extern "C" int tvae_encode_bwd(const void* d_latent, const void* latent, const v
     else if (dWe) TVAE_PROPAGATE(gemm_launch(gw, s));
     if (dbe) TVAE_PROPAGATE(colsum(dpre, rows, L, dbe, dtype, colscratch, s));
     return TVAE_OK;
+}
+}  // namespace
+
+extern "C" int tvae_encode_bwd(const void* d_latent, const void* latent, const void* h, int64_t h_stride_b,
+                               int64_t h_stride_s, const void* We, void* dh, void* dWe, void* dbe, int64_t B,
+                               int64_t S, int64_t n_eff, int64_t d, int64_t L, int dtype, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    return encode_bwd_impl(d_latent, nullptr, nullptr, latent, h, h_stride_b, h_stride_s, We, dh, dWe, dbe, B, S, n_eff, d,
+                           L, dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tvae_encode_bwd_sum(const void* d_latent, const void* d_latent_extra, const float* extra_scale,
+                                   const void* latent, const void* h, int64_t h_stride_b, int64_t h_stride_s,
+                                   const void* We, void* dh, void* dWe, void* dbe, int64_t B, int64_t S, int64_t n_eff,
+                                   int64_t d, int64_t L, int dtype, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
+    TVAE_REQUIRE(d_latent_extra && extra_scale, "encode_bwd_sum: null extra cotangent or scale");
+    return encode_bwd_impl(d_latent, d_latent_extra, extra_scale, latent, h, h_stride_b, h_stride_s, We, dh, dWe, dbe, B, S,
+                           n_eff, d, L, dtype, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -343,6 +343,19 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ dz,
     }
 }
 
+// dpre = (dz + *scale * dx) * (1 - z^2): the decoder's and the regulariser's shares of the latent cotangent meet here
+// (the regulariser's arrives unscaled, with its upstream gradient as a device scalar)
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_sum_kernel(const T* __restrict__ dz, const T* __restrict__ dx,
+                                                           const float* __restrict__ scale, const T* __restrict__ z,
+                                                           T* __restrict__ dpre, long long count) {
+    const float sc = *scale;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float zv = to_f32(z[i]);
+        dpre[i] = from_f32<T>(fmaf(sc, to_f32(dx[i]), to_f32(dz[i])) * (1.f - zv * zv));
+    }
+}
+
 // dh[b, n_eff:S, :] = 0, 16 B per lane.  `tail` = (S - n_eff) * d elements per sequence.
 __global__ __launch_bounds__(256) void zero_tail_kernel(char* __restrict__ dh, long long seq_bytes, long long head_bytes,
                                                         long long B) {
@@ -520,6 +533,21 @@ int tanh_bwd(const void* dz, const void* z, void* dpre, int64_t count, int dtype
     else
         hipLaunchKernelGGL(tanh_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)dz, (const bf16*)z,
                            (bf16*)dpre, (long long)count);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+int tanh_bwd_sum(const void* dz, const void* dx, const float* scale, const void* z, void* dpre, int64_t count, int dtype,
+                 hipStream_t s) {
+    if (count == 0) return TVAE_OK;
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == TVAE_F32)
+        hipLaunchKernelGGL(tanh_bwd_sum_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dz, (const float*)dx,
+                           scale, (const float*)z, (float*)dpre, (long long)count);
+    else
+        hipLaunchKernelGGL(tanh_bwd_sum_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)dz, (const bf16*)dx,
+                           scale, (const bf16*)z, (bf16*)dpre, (long long)count);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }

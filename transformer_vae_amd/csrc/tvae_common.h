@@ -133,6 +133,8 @@ int layernorm_bwd_fused(const void* dout, const void* r, const float* mean, cons
                         void* dr, void* dgamma, void* dbeta, int64_t rows, int64_t d, int dtype, float* scratch,
                         hipStream_t s);
 int tanh_bwd(const void* dz, const void* z, void* dpre, int64_t count, int dtype, hipStream_t s);
+int tanh_bwd_sum(const void* dz, const void* dx, const float* scale, const void* z, void* dpre, int64_t count,
+                 int dtype, hipStream_t s);
 int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype, hipStream_t s);
 
 // strip-wise MMD for latent sizes beyond the tile kernels (mmd_wide.hip)

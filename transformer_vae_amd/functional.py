@@ -292,7 +292,17 @@ class _BottleneckStep(torch.autograd.Function):
                                            _ptr(dz), _ptr(dWd), _ptr(dbd), _ptr(dgamma), _ptr(dbeta), N, L, d, code,
                                            _ptr(ws), ws.numel(), stream), "tvae_decode_bwd")
         dh = dWe = dbe = None
-        if want_z:
+        if (want_z and dz is not None and dz_mmd is not None and g_reg is not None and g_latent is None
+                and dz_mmd.dtype == dt and g_reg.dtype == torch.float32 and g_reg.numel() == 1):
+            # the usual training step: decoder's share + w * regulariser's share, added inside the tanh-backward pass
+            dh = torch.empty((B, S, d), dtype=dt, device=dev) if need[0] else None
+            dWe = torch.empty((L, d), dtype=dt, device=dev) if need[1] else None
+            dbe = torch.empty((L,), dtype=dt, device=dev) if need[2] else None
+            ws = _workspace(lib.tvae_encode_bwd_workspace_bytes(B, n_eff, d, L), dev)
+            _lib.check(lib.tvae_encode_bwd_sum(_ptr(dz), _ptr(dz_mmd), _ptr(g_reg), _ptr(z), _ptr(hc), hc.stride(0),
+                                               hc.stride(1), _ptr(Wc), _ptr(dh), _ptr(dWe), _ptr(dbe), B, S, n_eff, d, L,
+                                               code, _ptr(ws), ws.numel(), stream), "tvae_encode_bwd_sum")
+        elif want_z:
             # d latent = decoder's share + the regulariser's (scaled by its upstream gradient) + a direct one
             if g_reg is not None and dz_mmd is not None:
                 gm = g_reg.to(dz_mmd.dtype)
