@@ -129,7 +129,7 @@ int encode_bwd_impl(const void* d_latent, const void* d_latent_extra, const floa
     GemmDesc gh{}, gw{};
     if (dh) {
         // rows >= n_eff of every sequence: exact zeros (slice backward); rows < n_eff: d_pre @ We
-        TVAE_PROPAGATE(zero_tail_rows(dh, B, S, n_eff, d, dtype, s));
+        if (!dWe) TVAE_PROPAGATE(zero_tail_rows(dh, B, S, n_eff, d, dtype, s));     // (else it rides with the pair below)
         GemmDesc& g = gh;
         g.A = dpre; g.B = We; g.C = dh; g.M = (int)rows; g.N = (int)d; g.K = (int)L;
         g.a_kmajor = false; g.b_kmajor = true;
@@ -147,8 +147,12 @@ int encode_bwd_impl(const void* d_latent, const void* d_latent_extra, const floa
         g.epilogue = EPI_NONE; g.dtype = dtype; g.slab = slab1; g.slab_floats = slab_we;
         if (dbe && fuse_bias_grad(d, rows)) { g.colsum_out = dbe; dbe = nullptr; }   // dbe = dpre^T 1
     }
-    if (dh && dWe) TVAE_PROPAGATE(gemm_launch_pair(gh, gw, s));
-    else if (dh) TVAE_PROPAGATE(gemm_launch(gh, s));
+    if (dh && dWe) {
+        const ZeroTail zt = zero_tail_plan(dh, B, S, n_eff, d, dtype);
+        bool zt_done = false;
+        TVAE_PROPAGATE(gemm_launch_pair(gh, gw, s, &zt, &zt_done));
+        if (!zt_done) TVAE_PROPAGATE(zero_tail_rows(dh, B, S, n_eff, d, dtype, s));   // large products: its own launch
+    } else if (dh) TVAE_PROPAGATE(gemm_launch(gh, s));
     else if (dWe) TVAE_PROPAGATE(gemm_launch(gw, s));
     if (dbe) TVAE_PROPAGATE(colsum(dpre, rows, L, dbe, dtype, colscratch, s));
     return TVAE_OK;

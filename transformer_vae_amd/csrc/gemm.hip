@@ -191,6 +191,9 @@ __global__ TVAE_GEMM_BOUNDS void gemm_f32_mfma_kernel(GemmArgs a) {
 struct GemmPairArgs {
     GemmArgs p[2];
     int gx[2], gy[2], nblk0;
+    // encoder backward: the zero-fill of dh's untouched rows rides in the same launch -- its zt_blocks workgroups
+    // come FIRST in the grid, so the HBM-bound stores stream while the latency-bound products wait on their loads
+    ZeroTail zt; int zt_blocks;
 };
 
 template <typename T, int BKT>
@@ -198,6 +201,11 @@ __global__ TVAE_GEMM_BOUNDS void gemm_pair_kernel(GemmPairArgs q) {
     __shared__ float As[BKT][LDS_LD];
     __shared__ float Bs[BKT][LDS_LD];
     int b = blockIdx.x;
+    if (b < q.zt_blocks) {
+        zero_tail_body(q.zt, b % q.zt.gx, b / q.zt.gx, (int)threadIdx.x);
+        return;
+    }
+    b -= q.zt_blocks;
     if (b < q.nblk0) {
         const int bx = b % q.gx[0], t = b / q.gx[0];
         gemm_tile_body<T, false, true, EPI_NONE, BKT>(q.p[0], bx, t % q.gy[0], t / q.gy[0], As, Bs);
@@ -343,8 +351,8 @@ int gemm_launch(const GemmDesc& g, hipStream_t stream) {
 namespace {
 template <typename T>
 int launch_pair_typed(const GemmPairArgs& q, int nblk, hipStream_t s) {
-    if (q.p[0].deep) hipLaunchKernelGGL((gemm_pair_kernel<T, BK_DEEP>), dim3(nblk), dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((gemm_pair_kernel<T, BK>), dim3(nblk), dim3(256), 0, s, q);
+    if (q.p[0].deep) hipLaunchKernelGGL((gemm_pair_kernel<T, BK_DEEP>), dim3(nblk + q.zt_blocks), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((gemm_pair_kernel<T, BK>), dim3(nblk + q.zt_blocks), dim3(256), 0, s, q);
     const GemmArgs& a0 = q.p[0];
     const GemmArgs& a1 = q.p[1];
     auto rblocks = [](const GemmArgs& a) {
@@ -354,6 +362,7 @@ int launch_pair_typed(const GemmPairArgs& q, int nblk, hipStream_t s) {
     };
     if (a0.splits > 1 && a1.splits > 1) {
         GemmPairArgs r = q;
+        r.zt_blocks = 0;
         r.nblk0 = rblocks(a0);
         hipLaunchKernelGGL((gemm_reduce_pair_kernel<T>), dim3(r.nblk0 + rblocks(a1)), dim3(256), 0, s, r);
     } else if (a0.splits > 1) {
@@ -368,7 +377,8 @@ int launch_pair_typed(const GemmPairArgs& q, int nblk, hipStream_t s) {
 
 // g0: activation gradient (A row-major, B k-major), g1: weight gradient (A and B k-major), both without epilogue
 // and of one dtype.  Small launches share one grid; large ones (or other layouts) go out one after the other.
-int gemm_launch_pair(const GemmDesc& g0, const GemmDesc& g1, hipStream_t stream) {
+int gemm_launch_pair(const GemmDesc& g0, const GemmDesc& g1, hipStream_t stream, const ZeroTail* zt, bool* zt_done) {
+    if (zt_done) *zt_done = false;
     const bool shapes_ok = g0.M > 0 && g0.N > 0 && g1.M > 0 && g1.N > 0;
     const bool layouts_ok = !g0.a_kmajor && g0.b_kmajor && g1.a_kmajor && g1.b_kmajor &&
                             g0.epilogue == EPI_NONE && g1.epilogue == EPI_NONE && g0.dtype == g1.dtype;
@@ -385,6 +395,13 @@ int gemm_launch_pair(const GemmDesc& g0, const GemmDesc& g1, hipStream_t stream)
         }
         if (nb[0] + nb[1] <= TVAE_PAIR_MAX && q.p[0].deep == q.p[1].deep) {      // (one K-tile depth per launch)
             q.nblk0 = (int)nb[0];
+            q.zt = ZeroTail{};
+            q.zt_blocks = 0;
+            if (zt && zt->gx > 0 && zt_done) {
+                q.zt = *zt;
+                q.zt_blocks = zt->gx * zt->gy;
+                *zt_done = true;
+            }
             if (g0.dtype == TVAE_F32) return launch_pair_typed<float>(q, (int)(nb[0] + nb[1]), stream);
             if (g0.dtype == TVAE_BF16) return launch_pair_typed<bf16>(q, (int)(nb[0] + nb[1]), stream);
             return fail(TVAE_ERR_ARG, "gemm: unknown dtype %d", g0.dtype);

@@ -356,24 +356,9 @@ __global__ __launch_bounds__(256) void tanh_bwd_sum_kernel(const T* __restrict__
     }
 }
 
-// dh[b, n_eff:S, :] = 0, 16 B per lane.  `tail` = (S - n_eff) * d elements per sequence.
-__global__ __launch_bounds__(256) void zero_tail_kernel(char* __restrict__ dh, long long seq_bytes, long long head_bytes,
-                                                        long long B) {
-    // grid.y walks sequences, grid.x * 256 threads stride over the tail of one sequence
-    const long long tail = seq_bytes - head_bytes;
-    for (long long b = blockIdx.y; b < B; b += gridDim.y) {
-        char* base = dh + b * seq_bytes + head_bytes;
-        // leading bytes up to 16-B alignment, then uint4 stores, then the remainder
-        const long long mis = (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
-        const long long lead = mis < tail ? mis : tail;
-        const long long nvec = (tail - lead) / 16;
-        const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x;
-        if (t0 < lead) base[t0] = 0;
-        uint4* v = reinterpret_cast<uint4*>(base + lead);
-        for (long long i = t0; i < nvec; i += (long long)gridDim.x * 256) v[i] = make_uint4(0, 0, 0, 0);
-        const long long done = lead + nvec * 16;
-        if (t0 < tail - done) base[done + t0] = 0;
-    }
+// dh[b, n_eff:S, :] = 0 (zero_tail_body, tvae_common.h)
+__global__ __launch_bounds__(256) void zero_tail_kernel(ZeroTail z) {
+    zero_tail_body(z, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x);
 }
 
 inline int row_blocks(int64_t rows) { return (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
@@ -552,11 +537,15 @@ int tanh_bwd_sum(const void* dz, const void* dx, const float* scale, const void*
     return TVAE_OK;
 }
 
-int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype, hipStream_t s) {
-    if (S <= n_eff || B == 0) return TVAE_OK;
+ZeroTail zero_tail_plan(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype) {
+    ZeroTail z{};
+    if (S <= n_eff || B == 0) return z;       // gx == 0
     const int64_t esz = dtype == TVAE_F32 ? 4 : 2;
-    const long long seq_bytes = S * d * esz, head_bytes = n_eff * d * esz;
-    const long long tail_vec = (seq_bytes - head_bytes) / 16 + 1;
+    z.dh = static_cast<char*>(dh);
+    z.seq_bytes = S * d * esz;
+    z.head_bytes = n_eff * d * esz;
+    z.B = B;
+    const long long tail_vec = (z.seq_bytes - z.head_bytes) / 16 + 1;
     // enough workgroups to fill the chip: x over one sequence's tail, y over sequences
     int gx = (int)((tail_vec + 255) / 256);
     if (gx > 64) gx = 64;
@@ -565,7 +554,14 @@ int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int
     const int want = 4096 / gx;
     if (gy > want) gy = want;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL(zero_tail_kernel, dim3(gx, gy), dim3(256), 0, s, (char*)dh, seq_bytes, head_bytes, (long long)B);
+    z.gx = gx; z.gy = gy;
+    return z;
+}
+
+int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype, hipStream_t s) {
+    const ZeroTail z = zero_tail_plan(dh, B, S, n_eff, d, dtype);
+    if (z.gx == 0) return TVAE_OK;
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(z.gx, z.gy), dim3(256), 0, s, z);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }

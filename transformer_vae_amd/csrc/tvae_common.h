@@ -91,6 +91,30 @@ struct RowMap {
 };
 inline RowMap dense_rows(long long ld) { return RowMap{ld, 0, 1}; }
 
+// ---- zero-fill of dh[:, n_eff:, :] (the rows the latent slice never touched), 16 B per lane --------------
+// One virtual grid (gx, gy): x * 256 threads stride over the tail of one sequence, y walks the sequences.
+// Shared by zero_tail_kernel (rowops.hip) and the backward GEMM pair launch, whose extra workgroups run it.
+struct ZeroTail {
+    char* dh; long long seq_bytes, head_bytes, B;
+    int gx, gy;     // gx * gy workgroups of 256 threads; gx == 0: nothing to do
+};
+__device__ __forceinline__ void zero_tail_body(const ZeroTail& z, int bx, int by, int tid) {
+    const long long tail = z.seq_bytes - z.head_bytes;
+    for (long long b = by; b < z.B; b += z.gy) {
+        char* base = z.dh + b * z.seq_bytes + z.head_bytes;
+        // leading bytes up to 16-B alignment, then uint4 stores, then the remainder
+        const long long mis = (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
+        const long long lead = mis < tail ? mis : tail;
+        const long long nvec = (tail - lead) / 16;
+        const long long t0 = (long long)bx * 256 + tid;
+        if (t0 < lead) base[t0] = 0;
+        uint4* v = reinterpret_cast<uint4*>(base + lead);
+        for (long long i = t0; i < nvec; i += (long long)z.gx * 256) v[i] = make_uint4(0, 0, 0, 0);
+        const long long done = lead + nvec * 16;
+        if (t0 < tail - done) base[done + t0] = 0;
+    }
+}
+
 // ---- internal launchers (one translation unit each) -----------------------------------
 enum Epilogue { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_TANH = 2 };
 
@@ -112,7 +136,9 @@ struct GemmDesc {
 int64_t gemm_slab_floats(int M, int N, int K);
 int gemm_launch(const GemmDesc& g, hipStream_t stream);
 // activation-gradient + weight-gradient products of one projection; one launch when both are small
-int gemm_launch_pair(const GemmDesc& g_act, const GemmDesc& g_weight, hipStream_t stream);
+// `zt` (nullable): a zero-fill that may ride in the same launch (its workgroups come first); *zt_done says whether it did
+int gemm_launch_pair(const GemmDesc& g_act, const GemmDesc& g_weight, hipStream_t stream,
+                     const ZeroTail* zt = nullptr, bool* zt_done = nullptr);
 
 // row-wise / column-wise helpers (rowops.hip)
 int layernorm_fwd(const void* r, const void* gamma, const void* beta, float eps, void* out,
@@ -136,6 +162,7 @@ int tanh_bwd(const void* dz, const void* z, void* dpre, int64_t count, int dtype
 int tanh_bwd_sum(const void* dz, const void* dx, const float* scale, const void* z, void* dpre, int64_t count,
                  int dtype, hipStream_t s);
 int zero_tail_rows(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype, hipStream_t s);
+ZeroTail zero_tail_plan(void* dh, int64_t B, int64_t S, int64_t n_eff, int64_t d, int dtype);   // gx == 0: nothing to fill
 
 // strip-wise MMD for latent sizes beyond the tile kernels (mmd_wide.hip)
 int64_t mmd_wide_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad);
