@@ -918,3 +918,36 @@ def test_fused_step_is_bypassed_when_it_must_be():
     assert not ident._can_fuse(torch.from_numpy(h2).to(dev()), None)
     out = ident(input_encoding=torch.from_numpy(h2).to(dev()))
     assert out.reconstructed_encoding is out.latent
+
+
+def test_calls_run_with_the_tensors_device_current(monkeypatch):
+    """A module on another device than the current one: the host makes the tensors' device current around the C-ABI
+    calls (HIP resolves kernels for the CURRENT device).  One-GPU boxes cannot hold the mismatch for real, so the
+    current-device query is faked and the guard's entry is observed; the numbers must not change."""
+    from transformer_vae_amd import functional as F
+    rs = np.random.RandomState(3)
+    a, b = rs.standard_normal((9, 33)).astype(np.float32), rs.standard_normal((9, 33)).astype(np.float32)
+    ta, tb = torch.from_numpy(a).to(dev()), torch.from_numpy(b).to(dev())
+    want = F.slerp(0.3, ta, tb)
+    z = torch.tanh(torch.from_numpy(a)).to(dev()).requires_grad_(True)
+    loss0 = F.mmd_reg_loss(z, tb, 3, 3)
+    loss0.backward()
+    g0 = z.grad.clone()
+    entered = []
+    real_guard = torch.cuda.device
+
+    class Spy(real_guard):
+        def __enter__(self):
+            entered.append(self.idx)
+            return super().__enter__()
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 5)
+    monkeypatch.setattr(torch.cuda, "device", Spy)
+    got = F.slerp(0.3, ta, tb)
+    z.grad = None
+    loss1 = F.mmd_reg_loss(z, tb, 3, 3)
+    loss1.backward()
+    monkeypatch.undo()
+    assert entered and set(entered) == {0}
+    assert len(entered) >= 3                      # slerp, MMD forward, MMD backward
+    assert torch.equal(got, want) and torch.equal(loss0, loss1) and torch.equal(z.grad, g0)

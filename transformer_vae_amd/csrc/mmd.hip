@@ -799,13 +799,11 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
 template <int NB, int WAVES, bool GRAD>
 int launch_tile(const MmdArgs& a, int nblocks, hipStream_t s) {
     constexpr int lds_bytes = TileLds<NB, WAVES>::BYTES;
-    static std::once_flag once;
-    static hipError_t attr_status = hipSuccess;
-    std::call_once(once, [] {
-        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_tile_kernel<NB, WAVES, GRAD>),
+    static PerDeviceOnce once;
+    TVAE_CHECK_HIP(per_device_once(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_tile_kernel<NB, WAVES, GRAD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    });
-    TVAE_CHECK_HIP(attr_status);
+    }));
     hipLaunchKernelGGL((mmd_tile_kernel<NB, WAVES, GRAD>), dim3(nblocks), dim3(64 * WAVES), lds_bytes, s, a);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
@@ -814,13 +812,11 @@ int launch_tile(const MmdArgs& a, int nblocks, hipStream_t s) {
 template <int NB>
 int launch_tile_both(const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
     constexpr int lds_bytes = TileLds<NB, 1>::BYTES;
-    static std::once_flag once;
-    static hipError_t attr_status = hipSuccess;
-    std::call_once(once, [] {
-        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_tile_both_kernel<NB>),
+    static PerDeviceOnce once;
+    TVAE_CHECK_HIP(per_device_once(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_tile_both_kernel<NB>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    });
-    TVAE_CHECK_HIP(attr_status);
+    }));
     hipLaunchKernelGGL((mmd_tile_both_kernel<NB>), dim3(nwg0 + nwg1), dim3(64), lds_bytes, s, a, nwg0);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;

@@ -442,13 +442,11 @@ constexpr int debug_lds_pad() { return 0; }
 template <int KB, int RT, bool GRAD>
 int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
     constexpr int lds_bytes = Bf16Lds<KB, RT, GRAD>::BYTES;
-    static std::once_flag once;
-    static hipError_t attr_status = hipSuccess;
-    std::call_once(once, [] {
-        attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD>),
+    static PerDeviceOnce once;
+    TVAE_CHECK_HIP(per_device_once(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes + kDebugLdsPadMax);
-    });
-    TVAE_CHECK_HIP(attr_status);
+    }));
     hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD>), dim3(nblocks), dim3(256), lds_bytes + debug_lds_pad(), s, a);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/tvae_hip.h"
@@ -72,6 +73,21 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// Function attributes are per device: one bit per device ordinal remembers where `prepare` has succeeded
+// (nn.DataParallel drives several devices from one process; running `prepare` twice is harmless).
+struct PerDeviceOnce { std::atomic<uint64_t> done{0}; };
+template <typename F>
+inline hipError_t per_device_once(PerDeviceOnce& o, F&& prepare) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (o.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = prepare();
+    if (e == hipSuccess) o.done.fetch_or(bit, std::memory_order_release);
+    return e;
 }
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }

@@ -6,6 +6,7 @@ ROCm device; anything else raises (no CPU path).
 """
 from __future__ import annotations
 
+import functools
 from typing import Optional
 
 import torch
@@ -21,6 +22,24 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _on_tensor_device(fn):
+    """Run ``fn`` with the device of its first ROCm tensor argument current.
+
+    HIP resolves a kernel's code object for the CURRENT device, while the C ABI launches on the stream it is
+    given: a module living on cuda:1 called while cuda:0 is current would otherwise launch cuda:0's code object
+    on cuda:1's queue.  PyTorch's own ops guard the same way.  Free when the device is already current."""
+    @functools.wraps(fn)
+    def guarded(*args):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args)
+                break
+        return fn(*args)
+    return guarded
 
 
 def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
@@ -46,6 +65,7 @@ class _LatentEncode(torch.autograd.Function):
     """latent = tanh(h[:, :n] @ We^T + be)      (reference: autoencoders.py:21-22)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, h, We, be, n_tokens: int):
         _require_device(h, "latent encoder")
         if h.dim() != 3:
@@ -73,6 +93,7 @@ class _LatentEncode(torch.autograd.Function):
         return z if dt == out_dtype or torch.is_autocast_enabled() else z.to(out_dtype)
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dz):
         hc, Wc, z = ctx.saved_tensors
         B, S, d, L, n_eff, dt, h_dtype, w_dtype, b_dtype = ctx.meta
@@ -99,6 +120,7 @@ class _LatentDecode(torch.autograd.Function):
     """recon = [LayerNorm]( latent @ Wd^T + bd )    (reference: autoencoders.py:38-39, 66-67)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, z, Wd, bd, gamma, beta, eps: float):
         _require_device(z, "latent decoder")
         out_dtype = z.dtype
@@ -133,6 +155,7 @@ class _LatentDecode(torch.autograd.Function):
         return out if dt == out_dtype or torch.is_autocast_enabled() else out.to(out_dtype)
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dout):
         zc, Wc, gc, pre, mean, rstd = ctx.saved_tensors
         N, L, d, dt, lead, z_dtype, w_dtype, g_dtype = ctx.meta
@@ -170,6 +193,7 @@ class _MMDRegulariser(torch.autograd.Function):
     and returns the three partial sums, which the caller all-reduces."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float):
         _require_device(z_all, "MMD regulariser")
         dt = torch.bfloat16 if (z_all.dtype == torch.bfloat16 and y_all.dtype == torch.bfloat16) else torch.float32
@@ -199,6 +223,7 @@ class _MMDRegulariser(torch.autograd.Function):
         return loss, sums
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g_loss, _g_sums):
         (dz,) = ctx.saved_tensors
         g = (dz.float() * g_loss.float()).to(ctx.z_dtype)
@@ -214,6 +239,7 @@ class _BottleneckStep(torch.autograd.Function):
     else (autocast, hooks, a sharded regulariser, a given latent) asks for the separate nodes."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float):
         ctx.set_materialize_grads(False)
         dt = h.dtype
@@ -267,6 +293,7 @@ class _BottleneckStep(torch.autograd.Function):
         return z, recon.view(B, n_eff, d), loss
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g_latent, g_recon, g_reg):
         hc, Wc, z, Wdc, gc, pre, mean, rstd, dz_mmd = ctx.saved_tensors
         B, S, d, L, n_eff, dt = ctx.meta
@@ -330,6 +357,7 @@ class _Upsample(torch.autograd.Function):
     """HF funnel `upsample` as used on reconstructed_encoding (reference: model.py:265-271)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, x, stride: int, target_len: int, separate_cls: bool, truncate_seq: bool):
         _require_device(x, "upsample")
         if x.dim() != 3:
@@ -349,6 +377,7 @@ class _Upsample(torch.autograd.Function):
         return out if dt == x.dtype else out.to(x.dtype)
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g):
         B, n, d, stride, target_len, sep, trunc, dt, x_dtype = ctx.meta
         gc = g.to(dt).contiguous()
@@ -407,6 +436,11 @@ def upsample(x, stride: int, target_len: int, separate_cls: bool = True, truncat
 def slerp(ratio, t1, t2):
     """Drop-in for transformer_vae.utils.slerp (utils.py:17-34): `ratio` is a float or a (rows,) tensor;
     t1, t2 are (rows, dim).  Forward only — the result carries no autograd graph."""
+    return _slerp(t1, t2, ratio)
+
+
+@_on_tensor_device
+def _slerp(t1, t2, ratio):
     _require_device(t1, "slerp")
     if t1.dim() != 2 or t1.shape != t2.shape:
         raise ValueError(f"slerp expects two (rows, dim) tensors of equal shape, got {tuple(t1.shape)} and {tuple(t2.shape)}")
