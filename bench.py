@@ -252,13 +252,23 @@ def main():
     mmd_bf16 = args.mmd_dtype == "bf16"
     vae = make_vae(d, L, n, device, dtype, "global" if world > 1 else "local", world,
                    torch.bfloat16 if mmd_bf16 else None)
+    # rank r takes rows [r B/R, (r+1) B/R) of the SAME global tensors (generated on every rank from
+    # the same seeds, sliced, the rest released), so reg_loss is the same number at every N -- a built-in check
+    # of the sharded path against the single-GPU one.
     gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + cfg_id + 1000 * rank)
-    h = torch.randn((Bl, S, d), generator=gen, device=device, dtype=torch.float32).to(dtype).requires_grad_(True)
-    gen.manual_seed(4321 + cfg_id + 1000 * rank)
-    prior = torch.randn((Nl, L), generator=gen, device=device, dtype=torch.float32)
-    gen.manual_seed(99 + 1000 * rank)
-    g0 = (torch.randn((Bl, n_eff, d), generator=gen, device=device, dtype=torch.float32) / (N * d) ** 0.5).to(dtype)
+
+    def global_rows(shape, seed, lo, hi, div=None):
+        gen.manual_seed(seed)
+        full = torch.randn(shape, generator=gen, device=device, dtype=torch.float32)
+        if div is not None:
+            return full[lo:hi] / div
+        return full if world == 1 else full[lo:hi].clone()
+
+    h = global_rows((B, S, d), 1234 + cfg_id, rank * Bl, (rank + 1) * Bl).to(dtype).requires_grad_(True)
+    prior = global_rows((N, L), 4321 + cfg_id, rank * Nl, (rank + 1) * Nl)
+    g0 = global_rows((B, n_eff, d), 99, rank * Bl, (rank + 1) * Bl, (N * d) ** 0.5).to(dtype)
+    if world > 1:
+        torch.cuda.empty_cache()
     params = list(vae.parameters())
 
     events = HipEvents()
