@@ -344,6 +344,42 @@ def main():
                    "parallelism": f"row-sharded global-batch MMD x{world}" if world > 1 else "single GPU"},
         "reg_loss": reg, "roofline": roofline,
     }
+    if rank == 0 and world == 1 and others is not None and not mmd_bf16 and args.dtype == "fp32" and L > 192:
+        # the opt-in bf16 matrix-core MMD (EncoderDecoderVAE(mmd_dtype=torch.bfloat16): latents and prior rounded to
+        # bf16 for the regulariser only, 1e-2 parity class) on the SAME inputs -- reported beside the exact-fp32
+        # headline, never instead of it
+        try:
+            vae16 = make_vae(d, L, n, device, dtype, "local", 1, torch.bfloat16)
+            p16 = list(vae16.parameters())
+            ev16 = HipEvents()
+
+            def step16(timed):
+                h.grad = None
+                for p in p16:
+                    p.grad = None
+                if timed:
+                    lib.tvae_profile_next_mmd(*ev16.new_pair())
+                o = vae16(input_encoding=h, true_samples=prior)
+                (o.reg_loss * REG_W + (o.reconstructed_encoding * g0).sum()).backward()
+                return o
+
+            step16(False)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                o16 = step16(True)
+            fence()
+            sec16 = (time.perf_counter() - t1) / args.steps
+            k16 = float(np.mean(ev16.durations_ms()))
+            a16 = flops / (k16 * 1e-3) / 1e12
+            others.append({"workload": f"{args.config}: {label} -- opt-in bf16 matrix-core MMD", "value": B / sec16,
+                           "unit": "samples/s", "ms_per_step": sec16 * 1e3, "steps": args.steps, "hip_graph": False,
+                           "dtype": "f32+bf16-mmd", "reg_loss": float(o16.reg_loss.detach()),
+                           "roofline": {"bound": "mfma", "achieved": a16, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": a16 / PEAK_BF16_MFMA_TFLOPS, "kernel": "mmd_bf16_kernel", "kernel_ms": k16}})
+            del vae16, p16
+        except Exception as e:
+            others.append({"workload": f"{args.config} bf16 MMD", "hip_graph": False, "value": None, "error": repr(e)[:200]})
     if rank == 0:
         if others is not None:
             line["other_configs"] = others
