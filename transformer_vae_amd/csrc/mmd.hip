@@ -58,6 +58,15 @@ struct TileLds {
     static constexpr int WG_PER_CU = (160 * 1024) / BYTES;
 };
 
+#ifndef TVAE_SYNC_TILES
+#define TVAE_SYNC_TILES 1024
+#endif
+#ifndef TVAE_SYNC_POLLS
+#define TVAE_SYNC_POLLS 32
+#endif
+constexpr int SYNC_TILES = TVAE_SYNC_TILES;     // soft rendezvous period in column tiles (~6 ms at D = 768), a power of two
+constexpr int SYNC_POLLS = TVAE_SYNC_POLLS;     // polls (~1-2 us each) before a workgroup gives up waiting
+
 // One workgroup = WAVES waves owns 32 rows i of the kernel matrix and walks 16-point column tiles;
 // the feature dimension is sliced over the waves (DPAD = WAVES * SW).
 //
@@ -95,7 +104,8 @@ __device__ __forceinline__ void mmd_tile_body(const MmdArgs& a, const int block)
     const int bid = a.problem_base * per_problem + block;
     const int problem = GRAD ? 0 : bid / per_problem;
     const int rem = bid - problem * per_problem;
-    const int rb = rem / a.col_splits, sp = rem - rb * a.col_splits;
+    const int rb = a.sp_major ? rem % a.row_blocks : rem / a.col_splits;
+    const int sp = a.sp_major ? rem / a.row_blocks : rem - rb * a.col_splits;
     const int i0 = rb * ROWS_PER_WG;
 
     // ---- the 32 rows of this workgroup: this wave's feature slice, kept in registers ----
@@ -204,6 +214,33 @@ __device__ __forceinline__ void mmd_tile_body(const MmdArgs& a, const int block)
 #endif
     for (int tile = tb; tile < te; ++tile) {
         PHASE_MARK(5);
+        if constexpr (GRAD && WAVES > 1) {
+            // SOFT RENDEZVOUS.  Every workgroup streams the same column tiles; while the ~64 workgroups of an XCD
+            // stay within ~80 tiles of each other (4 MiB of L2) each tile leaves HBM once per XCD.  Left alone they
+            // drift apart (measured L2 -> fabric reads of this kernel: 2x the once-per-XCD minimum at N = 32 768,
+            // 21x at N = 131 072, 30x at BASELINE cfg4).  Every SYNC_TILES tiles the workgroups that were dispatched
+            // together (`sync_group` consecutive block indices = one resident set) count in and wait for each other
+            // -- for at most SYNC_POLLS polls, so a set that is not co-resident (shared GPU, last partial set) costs
+            // microseconds, never a hang.  Counters are per (set, epoch): nothing is ever reset or reused.
+            const int rel = tile - tb;
+            if (a.sync_ctr != nullptr && rel > 0 && (rel & (SYNC_TILES - 1)) == 0 && rel / SYNC_TILES <= a.sync_epochs) {
+                if (tid == 0) {
+                    // one rendezvous per XCD share of the set (workgroups go to the 8 XCDs round-robin by index;
+                    // were that ever not so, the sets would merely be different ones)
+                    const int grp = block / a.sync_group, x = block & 7;
+                    int left = a.launch_blocks - grp * a.sync_group;
+                    left = left < a.sync_group ? left : a.sync_group;
+                    const unsigned want = (unsigned)((left - x + 7) >> 3);
+                    unsigned* c = a.sync_ctr + ((long long)grp * 8 + x) * a.sync_epochs + (rel / SYNC_TILES - 1);
+                    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int poll = 0; poll < SYNC_POLLS; ++poll) {
+                        if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+        }
         const int atile = actual(tile);
         const int set = atile >= tps ? 1 : 0;
         const int p0 = (atile - set * (int)tps) * TILE_P;
@@ -706,7 +743,8 @@ struct Plan {
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
-    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, bytes;
+    int sync_epochs, sync_group, sync_groups;   // soft rendezvous of the gradient launch (sync_epochs == 0: off)
+    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, off_sync, bytes;
 };
 
 // (padded dimension, waves per workgroup, 16-column blocks per wave); DPAD = WAVES * 16 * NB
@@ -771,7 +809,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
         if (waste <= 1.0005) break;
     }
     p->col_splits = cs < 1 ? 1 : cs;
-#ifdef TVAE_PHASE_TIMING
+#if defined(TVAE_PHASE_TIMING) || defined(TVAE_DEBUG_ENV)
     if (getenv("TVAE_DEBUG_COL_SPLITS")) p->col_splits = atoi(getenv("TVAE_DEBUG_COL_SPLITS"));   // experiments only
 #endif
     int rpw = (p->n_pad + 511) / 512;
@@ -792,6 +830,18 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     p->off_sums = take((int64_t)(2 * p->row_blocks + p->row_blocks_g) * p->col_splits * 2 * 8);
     p->off_rowsum = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * 8 : 0);
     p->off_grad = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * p->DPAD * 4 : 0);
+    // soft rendezvous: multi-wave fp32 gradient launches whose workgroups stream at least two periods
+    p->sync_epochs = 0; p->sync_group = slots; p->sync_groups = 0;
+    if (want_grad && !bf16_tiles && p->WAVES > 1) {
+        const int64_t stream = 2ll * p->tiles_per_set / p->col_splits;          // shortest stream of a workgroup
+        const int64_t epochs = (stream - 1) / SYNC_TILES;
+        const int64_t groups = ((int64_t)p->row_blocks_g * p->col_splits + slots - 1) / slots;
+        if (epochs >= 1 && slots % 8 == 0 && groups * epochs <= (1 << 17)) { p->sync_epochs = (int)epochs; p->sync_groups = (int)groups; }
+    }
+#ifdef TVAE_DEBUG_ENV
+    if (getenv("TVAE_DEBUG_NO_SYNC")) p->sync_epochs = 0;          // experiments only
+#endif
+    p->off_sync = take((int64_t)p->sync_groups * 8 * p->sync_epochs * 4);
     p->bytes = off;
     return true;
 }
@@ -962,6 +1012,11 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     a.row_blocks = p.row_blocks; a.col_splits = p.col_splits; a.tiles_per_set = p.tiles_per_set;
     a.n_rows_pad = p.n_rows_pad;
     a.inv_d2 = (float)(1.0 / ((double)D * (double)D));
+    a.sp_major = p.sync_epochs > 0 ? 1 : 0;     // a resident set then shares ONE column range
+    a.sync_ctr = nullptr; a.sync_epochs = p.sync_epochs; a.sync_group = p.sync_group; a.launch_blocks = 0;
+#ifdef TVAE_DEBUG_ENV
+    if (getenv("TVAE_DEBUG_SP_MAJOR")) a.sp_major = atoi(getenv("TVAE_DEBUG_SP_MAJOR"));          // experiments only
+#endif
     const int sym_rows = p.narrow64 ? 64 : ROWS_PER_WG;      // row block of the symmetric y-y enumeration
     a.sym = (row_offset % sym_rows == 0 && (n_rows % sym_rows == 0 || row_offset + n_rows == n_total)) ? 1 : 0;
     a.wg_sums = reinterpret_cast<double*>(ws + p.off_sums);
@@ -970,6 +1025,8 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     // workgroups of the two problems (the bf16 gradient launch has its own, larger, row blocks)
     const int nwg_sum = p.row_blocks * p.col_splits;
     const int nwg0 = d_z ? p.row_blocks_g * p.col_splits : nwg_sum, nwg1 = nwg_sum;
+    if (d_z && p.sync_epochs > 0)        // arrival counters of the soft rendezvous (a memset node under graph capture)
+        TVAE_CHECK_HIP(hipMemsetAsync(ws + p.off_sync, 0, (size_t)p.sync_groups * 8 * p.sync_epochs * 4, s));
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
@@ -979,7 +1036,12 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
         TVAE_PROPAGATE(launch_tile_both_shape(p.DPAD, a, nwg0, nwg1, s));
     } else if (d_z) {
         a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks_g;
+        if (p.sync_epochs > 0) {
+            a.sync_ctr = reinterpret_cast<unsigned*>(ws + p.off_sync);
+            a.launch_blocks = nwg0;
+        }
         TVAE_PROPAGATE(launch_tiles<true>(p, a, nwg0, s));              // z rows: sums + gradient
+        a.sync_ctr = nullptr;
         a.problem_base = 1; a.sums_base = nwg0; a.row_blocks = p.row_blocks;
         TVAE_PROPAGATE(launch_tiles<false>(p, a, nwg1, s));    // y rows: sum only
     } else {

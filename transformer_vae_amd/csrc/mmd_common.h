@@ -14,6 +14,10 @@ struct MmdArgs {
     int row_blocks, col_splits, tiles_per_set, n_rows_pad;
     int problem_base;        // first problem of this launch (0: rows = z, 1: rows = y)
     int sums_base;           // bf16 kernels: index of this launch's first workgroup in wg_sums
+    int sp_major;            // workgroup order: 0 = the splits of a row block are neighbours, 1 = all row blocks of split 0 first
+    // soft rendezvous of the gradient launch (null: off): see mmd.hip "SOFT RENDEZVOUS"
+    unsigned* sync_ctr;      // [groups][sync_epochs] arrival counters, zeroed before the launch
+    int sync_epochs, sync_group, launch_blocks;
     int sym;                 // 1: the y-y problem visits each unordered pair of 32-row blocks once (weight 2)
     float inv_d2;
     double* wg_sums;         // [2 * row_blocks * col_splits][2]
