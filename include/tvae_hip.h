@@ -141,6 +141,11 @@ int tvae_decode_bwd(const void* d_recon, const void* latent, const void* Wd,
  * Any D: fused tile kernels up to 1024 (fp32-input MFMA; bf16 MFMA when dtype is TVAE_BF16 and
  * D > 192), strip-wise through the projection GEMM beyond.  n_total < 2^30. */
 int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad);
+/* Same, for the dtype the call will be made with (TVAE_F32 / TVAE_BF16).  tvae_mmd_workspace_bytes covers
+ * either; bf16 calls with large column sets use one gradient slab per ~24 MB column chunk (up to 32 GiB in all),
+ * which an fp32 caller need not pay for.  Like the query above it has no counterpart in the reference, which
+ * materialises (N, N, D) temporaries instead (autoencoders.py:117-126). */
+int64_t tvae_mmd_workspace_bytes_for(int64_t n_total, int64_t n_rows, int64_t D, int want_grad, int dtype);
 int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all,
                      int64_t n_total, int64_t row_offset, int64_t n_rows, int64_t D, int dtype,
                      double* sums3, float* loss, double loss_scale,

@@ -39,7 +39,12 @@ def test_version_and_workspace_queries(lib):
     small = lib.tvae_mmd_workspace_bytes(350, 350, 77, 1)
     big = lib.tvae_mmd_workspace_bytes(245760, 245760, 768, 1)
     shard = lib.tvae_mmd_workspace_bytes(245760, 30720, 768, 1)
-    assert 0 < small < shard <= big < 8 * 2 ** 30
+    assert 0 < small < shard <= big
+    # the dtype-aware query: fp32 needs a few GiB at cfg4; bf16 adds one gradient slab per column chunk (<= 32 GiB)
+    f32 = lib.tvae_mmd_workspace_bytes_for(245760, 245760, 768, 1, 0)
+    b16 = lib.tvae_mmd_workspace_bytes_for(245760, 245760, 768, 1, 1)
+    assert 0 < f32 < 8 * 2 ** 30 and f32 <= big and 0 < b16 <= big < 40 * 2 ** 30
+    assert lib.tvae_mmd_workspace_bytes_for(350, 350, 77, 1, 7) == -1
     assert lib.tvae_mmd_workspace_bytes(350, 350, 77, 0) <= small
     assert lib.tvae_mmd_workspace_bytes(100, 100, 5000, 1) > 0         # latent_size > 1024: strip-wise route
     assert lib.tvae_mmd_workspace_bytes(0, 0, 77, 1) == -1

@@ -39,6 +39,7 @@ SIGNATURES = {
     "tvae_decode_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int,
                                _vp, _i64, _vp]),
     "tvae_mmd_workspace_bytes": (_i64, [_i64, _i64, _i64, _int]),
+    "tvae_mmd_workspace_bytes_for": (_i64, [_i64, _i64, _i64, _int, _int]),
     "tvae_profile_next_mmd": (_int, [_vp, _vp]),
     "tvae_upsample_out_len": (_i64, [_i64, _i64, _i64, _int, _int]),
     "tvae_upsample_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _vp]),

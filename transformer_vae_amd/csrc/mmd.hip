@@ -743,6 +743,7 @@ struct Plan {
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
+    int sp_major;     // 1: split-major workgroup order (see make_plan)
     int sync_epochs, sync_group, sync_groups;   // soft rendezvous of the gradient launch (sync_epochs == 0: off)
     int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, off_sync, bytes;
 };
@@ -809,6 +810,25 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
         if (waste <= 1.0005) break;
     }
     p->col_splits = cs < 1 ? 1 : cs;
+    // bf16 tiles: a step lasts ~1 us, less than an HBM round trip, so the kernel runs at the pace of its L2 misses.
+    // While the column data (both sets) fits the 256 MB Infinity Cache those are cheap; past it the kernel lost a
+    // quarter of its rate (N = 65 536 -> 98 304 at D = 768: 930 -> 750 TFLOP/s).  So split the columns into chunks of
+    // ~24 MB and run split-major: all row blocks of chunk 0, then chunk 1, ... -- every resident set re-reads a
+    // chunk the previous sets left in the cache (cfg4 size: 641 -> 492 ms; sweep in DESIGN 4.1b).  Costs one
+    // gradient slab per split (capped at 32 GiB).
+    p->sp_major = 0;
+    if (bf16_tiles) {
+        const int64_t col_bytes = 2ll * p->n_pad * p->DPAD * 2;
+        if (col_bytes > (64ll << 20)) {
+            int64_t want = (col_bytes + (24ll << 20) - 1) / (24ll << 20);
+            const int64_t hard_max = p->tiles_per_set / 16 < 64 ? p->tiles_per_set / 16 : 64;   // >= 16 tiles of a set per split
+            if (want > hard_max) want = hard_max;
+            const int64_t slab = (int64_t)p->n_rows_pad * p->DPAD * 4;
+            while (want > 1 && want_grad && want * slab > (32ll << 30)) --want;
+            if (want > p->col_splits) p->col_splits = (int)want;
+            p->sp_major = 1;
+        }
+    }
 #if defined(TVAE_PHASE_TIMING) || defined(TVAE_DEBUG_ENV)
     if (getenv("TVAE_DEBUG_COL_SPLITS")) p->col_splits = atoi(getenv("TVAE_DEBUG_COL_SPLITS"));   // experiments only
 #endif
@@ -946,6 +966,16 @@ extern "C" int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int
     return p.bytes;
 }
 
+extern "C" int64_t tvae_mmd_workspace_bytes_for(int64_t n_total, int64_t n_rows, int64_t D, int want_grad, int dtype) {
+    if (dtype != TVAE_F32 && dtype != TVAE_BF16) return -1;
+    if (n_total > 0 && n_rows > 0 && D > 1024 && n_total < (1ll << 30))
+        return mmd_wide_workspace_bytes(n_total, n_rows, D, want_grad != 0);
+    Plan p;
+    if (n_total <= 0 || n_rows <= 0 || D <= 0 ||
+        !make_plan(n_total, n_rows, D, want_grad != 0, use_bf16_tiles(dtype, D), &p)) return -1;
+    return p.bytes;
+}
+
 extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
                                 int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
                                 double loss_scale, void* d_z, double grad_scale, void* workspace,
@@ -1012,7 +1042,7 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     a.row_blocks = p.row_blocks; a.col_splits = p.col_splits; a.tiles_per_set = p.tiles_per_set;
     a.n_rows_pad = p.n_rows_pad;
     a.inv_d2 = (float)(1.0 / ((double)D * (double)D));
-    a.sp_major = p.sync_epochs > 0 ? 1 : 0;     // a resident set then shares ONE column range
+    a.sp_major = (p.sync_epochs > 0 || p.sp_major) ? 1 : 0;     // a resident set then shares ONE column range
     a.sync_ctr = nullptr; a.sync_epochs = p.sync_epochs; a.sync_group = p.sync_group; a.launch_blocks = 0;
 #ifdef TVAE_DEBUG_ENV
     if (getenv("TVAE_DEBUG_SP_MAJOR")) a.sp_major = atoi(getenv("TVAE_DEBUG_SP_MAJOR"));          // experiments only

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
     const int per_problem = a.row_blocks * a.col_splits;
     const int problem = GRAD ? 0 : a.problem_base + (int)blockIdx.x / per_problem;
     const int rem = (int)blockIdx.x - (problem - a.problem_base) * per_problem;
-    const int rb = rem / a.col_splits, sp = rem - rb * a.col_splits;
+    const int rb = a.sp_major ? rem % a.row_blocks : rem / a.col_splits;
+    const int sp = a.sp_major ? rem / a.row_blocks : rem - rb * a.col_splits;
     const int i0 = rb * ROWS;
     const long long bid = (long long)a.sums_base + blockIdx.x;
 

@@ -206,7 +206,7 @@ class _MMDRegulariser(torch.autograd.Function):
         want_grad = bool(ctx.needs_input_grad[0])
         dev = za.device
         lib = _lib.lib()
-        ws_bytes = lib.tvae_mmd_workspace_bytes(n_total, n_rows, D, int(want_grad))
+        ws_bytes = lib.tvae_mmd_workspace_bytes_for(n_total, n_rows, D, int(want_grad), _DTYPES[dt])
         if ws_bytes < 0:
             raise RuntimeError(f"MMD regulariser: unsupported problem size (n_total={n_total}, n_rows={n_rows}, D={D})")
         ws = _workspace(ws_bytes, dev)
@@ -264,7 +264,7 @@ class _BottleneckStep(torch.autograd.Function):
         ya = prior.reshape(N, L).to(mdt).contiguous()
         want_grad = any(ctx.needs_input_grad[:3])
         loss_scale, grad_scale = mmd_scales(B, n_eff, N, L)
-        ws_bytes = lib.tvae_mmd_workspace_bytes(N, N, L, int(want_grad))
+        ws_bytes = lib.tvae_mmd_workspace_bytes_for(N, N, L, int(want_grad), _DTYPES[mdt])
         if ws_bytes < 0:
             raise RuntimeError(f"MMD regulariser: unsupported problem size (n_total={N}, D={L})")
         ws = _workspace(ws_bytes, dev)
