@@ -951,3 +951,24 @@ def test_calls_run_with_the_tensors_device_current(monkeypatch):
     assert entered and set(entered) == {0}
     assert len(entered) >= 3                      # slerp, MMD forward, MMD backward
     assert torch.equal(got, want) and torch.equal(loss0, loss1) and torch.equal(z.grad, g0)
+
+
+@pytest.mark.parametrize("N,D,dtype", [(32768, 768, torch.float32), (20480, 1024, torch.float32), (40000, 768, torch.bfloat16)])
+def test_mmd_gradient_at_scale_sampled_rows(N, D, dtype):
+    """Sizes at which the large-problem machinery is on -- fp32: the per-XCD soft rendezvous and split-major
+    workgroup order of the gradient launch (streams of > 1 024 column tiles); bf16: ~24 MB column chunks, one
+    gradient slab each.  The full call's gradient, on a sample of rows spread over the row blocks, against the
+    oracle in fp64 on the same (rounded) inputs."""
+    from transformer_vae_amd import functional as F
+    gen = torch.Generator(device=dev()).manual_seed(3 * N + D)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev())).to(dtype)
+    y = torch.randn((N, D), generator=gen, device=dev()).to(dtype)
+    zt = z.clone().requires_grad_(True)
+    F.mmd_reg_loss(zt, y, batch_size=1, n_latents=1).backward()
+    rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(N // 2 - 7, N // 2 + 30), np.arange(N - 45, N),
+                                     np.random.RandomState(N).randint(0, N, 80)]))
+    z64, y64 = z.double().cpu().numpy(), y.double().cpu().numpy()
+    gref = orc.mmd_grad_latent_rows(z64[rows], z64, y64)
+    got = zt.grad.float().cpu().numpy()[rows]
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert np.abs(got - gref).max() <= tol * np.abs(gref).max(), (np.abs(got - gref).max(), np.abs(gref).max())
