@@ -107,17 +107,26 @@ def cpu_baseline(cfg_name, world):
         return {"value": B / sec, "unit": "samples/s", "cores": threads, "kind": "port",
                 "sample": f"literal reference op sequence (oracle/literal_torch.py), whole batch B={B}, "
                           f"median of {len(ts)} steps, torch CPU fp32"}
-    # Gram-form restatement, row sample
-    rows = 256 if N > 100_000 else 512
+    # Gram-form restatement, row sample: a 256-row probe sizes the sample for 10-20 s of CPU work (bounded by N)
     rs = np.random.RandomState(4321 + cfg_id)
     z_all = np.tanh(rs.standard_normal((N, L))).astype(np.float32)
     y_all = rs.standard_normal((N, L)).astype(np.float32)
-    t0 = time.perf_counter()
-    orc.mmd_partial_sums(z_all[:rows], y_all[:rows], z_all, y_all, chunk=rows)
-    orc.mmd_grad_latent_rows(z_all[:rows], z_all, y_all, chunk=rows)
-    t_mmd = (time.perf_counter() - t0) * (N / rows)
-    # projections on the same row sample (slice-first restatement), fwd + analytic bwd
-    bs = max(1, rows // n_eff)
+
+    def mmd_sample(rows):
+        t0 = time.perf_counter()
+        orc.mmd_partial_sums(z_all[:rows], y_all[:rows], z_all, y_all, chunk=min(rows, 512))
+        orc.mmd_grad_latent_rows(z_all[:rows], z_all, y_all, chunk=min(rows, 512))
+        return time.perf_counter() - t0
+
+    rows = min(N, 256)
+    t_probe = mmd_sample(rows)
+    want = min(N, int(rows * 20.0 / max(t_probe, 1e-3)) // 256 * 256)
+    if want > rows:
+        rows = want
+        t_probe = mmd_sample(rows)
+    t_mmd = t_probe * (N / rows)
+    # projections on the same share of the batch (slice-first restatement), fwd + analytic bwd
+    bs = max(1, min(B, rows // n_eff))
     h, p, prior, g0 = orc.synth_inputs(bs, min(S, n_eff), d, n, L, cfg_id, "")
     t0 = time.perf_counter()
     fwd = orc.bottleneck_forward(h, p, n, None, use_reg_loss=False)
