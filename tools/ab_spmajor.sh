@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage (GPU box): tools/ab_spmajor.sh N D "<cs|0> <sp_major|-> [nosync]" ...   -- time + L2->fabric read bytes of the MMD call
-# under workgroup-order / column-split overrides (variant build with -DTVAE_DEBUG_ENV)
+# under workgroup-order / column-split overrides.  Variant libraries (built here, before the GPU call):
+#   tools/build_variant.sh dbgenv -DTVAE_DEBUG_ENV        (env overrides TVAE_DEBUG_COL_SPLITS / _SP_MAJOR / _NO_SYNC)
+#   AB_LIB=<name> picks another transformer_vae_amd/variants/libtvae_<name>.so (e.g. one built from an older commit)
 N=$1; D=$2; shift 2
 export TVAE_LIB_OVERRIDE=$GRAFT_REPO_ROOT/transformer_vae_amd/variants/libtvae_${AB_LIB:-dbgenv}.so
 cd /tmp && export TMPDIR=/tmp
