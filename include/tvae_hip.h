@@ -152,6 +152,22 @@ int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all,
                      void* d_z, double grad_scale,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Allocation-free variant of tvae_mmd_fwd_bwd.  NO counterpart in the reference: it exists for callers that
+ * cannot allocate device memory around the call (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  Same arguments and results as tvae_mmd_fwd_bwd minus the workspace pair: the scratch
+ * (padded copies, norms, partial sums, gradient slabs, rendezvous counters) lives in a device array inside the
+ * library, TVAE_MMD_STATIC_SCRATCH_BYTES per GPU the library runs on, held until the process ends.  Problems
+ * whose tvae_mmd_workspace_bytes_for() exceeds that are rejected with TVAE_ERR_WORKSPACE (the reference's
+ * shipped shapes up to BASELINE cfg3, N = 5120 x D = 77, fit).  Calls no hipMalloc/hipFree.  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two streams, two host threads) race; serialise them.
+ * The device of `stream` must be current.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress): make it once outside graph capture. */
+#define TVAE_MMD_STATIC_SCRATCH_BYTES (32ll << 20)
+int tvae_mmd_fwd_bwd_static(const void* z_all, const void* y_all,
+                            int64_t n_total, int64_t row_offset, int64_t n_rows, int64_t D, int dtype,
+                            double* sums3, float* loss, double loss_scale,
+                            void* d_z, double grad_scale, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Next to the path.
  *

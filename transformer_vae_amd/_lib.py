@@ -46,6 +46,7 @@ SIGNATURES = {
     "tvae_upsample_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _vp]),
     "tvae_slerp": (_int, [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _int, _vp]),
     "tvae_mmd_fwd_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp, _i64, _vp]),
+    "tvae_mmd_fwd_bwd_static": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp]),
 }
 
 _lock = threading.Lock()

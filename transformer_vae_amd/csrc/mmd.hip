@@ -976,10 +976,11 @@ extern "C" int64_t tvae_mmd_workspace_bytes_for(int64_t n_total, int64_t n_rows,
     return p.bytes;
 }
 
-extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
-                                int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
-                                double loss_scale, void* d_z, double grad_scale, void* workspace,
-                                int64_t workspace_bytes, void* stream) {
+namespace {
+int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
+                     int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
+                     double loss_scale, void* d_z, double grad_scale, void* workspace,
+                     int64_t workspace_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     TVAE_REQUIRE(z_all && y_all && sums3 && workspace, "mmd: null pointer argument");
     TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16, "mmd: unknown dtype %d", dtype);
@@ -1094,4 +1095,59 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
     else hipLaunchKernelGGL((mmd_finalize_kernel<bf16, bf16>), dim3((unsigned)fb), dim3(256), 0, s, f);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
+}
+}  // namespace
+
+extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
+                                int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
+                                double loss_scale, void* d_z, double grad_scale, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    return mmd_fwd_bwd_impl(z_all, y_all, n_total, row_offset, n_rows, D, dtype, sums3, loss, loss_scale, d_z, grad_scale,
+                            workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Allocation-free variant (no counterpart in the reference; for callers that cannot allocate: code under HIP graph
+// capture, tight serving loops).  Same kernels as tvae_mmd_fwd_bwd; the workspace is a file-scope device array that
+// every GPU the library runs on holds until the process ends.
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr int64_t SCRATCH_BYTES = TVAE_MMD_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+// `scratch` is a host-side stand-in in host code, never a device address: each device's copy is looked up once
+// (with that device current) and only the looked-up pointer is ever handed to kernels / memsets.
+constexpr int MAX_DEVICES = 64;
+std::atomic<void*> g_scratch_ptr[MAX_DEVICES];
+
+int scratch_of_current_device(void** out) {
+    int dev = 0;
+    TVAE_CHECK_HIP(hipGetDevice(&dev));
+    TVAE_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "mmd_static: device ordinal %d beyond %d", dev, MAX_DEVICES);
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        TVAE_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        TVAE_REQUIRE(p != nullptr, "mmd_static: hipGetSymbolAddress returned a null scratch address");
+        g_scratch_ptr[dev].store(p, std::memory_order_release);     // racing first calls store the same address
+    }
+    *out = p;
+    return TVAE_OK;
+}
+}  // namespace
+
+extern "C" int tvae_mmd_fwd_bwd_static(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
+                                       int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
+                                       double loss_scale, void* d_z, double grad_scale, void* stream) {
+    TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16, "mmd_static: unknown dtype %d", dtype);
+    const int64_t need = tvae_mmd_workspace_bytes_for(n_total, n_rows, D, d_z != nullptr, dtype);
+    TVAE_REQUIRE(need >= 0, "mmd_static: unsupported problem (n_total=%lld n_rows=%lld D=%lld)", (long long)n_total,
+                 (long long)n_rows, (long long)D);
+    if (need > SCRATCH_BYTES)
+        return fail(TVAE_ERR_WORKSPACE,
+                    "mmd_static: this problem needs %lld B of scratch, the built-in buffer holds %lld B "
+                    "(n_total=%lld n_rows=%lld D=%lld): use tvae_mmd_fwd_bwd with a caller workspace",
+                    (long long)need, (long long)SCRATCH_BYTES, (long long)n_total, (long long)n_rows, (long long)D);
+    void* ws = nullptr;
+    TVAE_PROPAGATE(scratch_of_current_device(&ws));
+    return mmd_fwd_bwd_impl(z_all, y_all, n_total, row_offset, n_rows, D, dtype, sums3, loss, loss_scale, d_z, grad_scale,
+                            ws, SCRATCH_BYTES, stream);
 }
