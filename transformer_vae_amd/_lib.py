@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libtvae_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "tvae_hip.h")
 
-TVAE_F32, TVAE_BF16 = 0, 1
+TVAE_F32, TVAE_BF16, TVAE_F32_STRICT = 0, 1, 2      # TVAE_F32_STRICT: tvae_mmd_* only (include/tvae_hip.h)
 
 _i64, _vp, _int, _f32, _f64 = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
 

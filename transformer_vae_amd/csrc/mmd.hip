@@ -531,12 +531,21 @@ __global__ __launch_bounds__(64, 2) void mmd_tile_both_kernel(MmdArgs a, int nwg
 
 // ---- prep: zero-padded copies (row stride DPAD; fp32, or bf16 for the bf16 kernels), squared norms,
 //      per-wave column sums ----
-template <typename T, typename TC>
+// SPLIT (TC = bf16, T = float): dst holds hi = bf16(v), and dst + lo_off holds lo = bf16(v - hi)
+template <typename TC, bool SPLIT>
+__device__ __forceinline__ void prep_store(TC* dst, long long idx, long long lo_off, float v) {
+    const TC hi = from_f32<TC>(v);
+    dst[idx] = hi;
+    if constexpr (SPLIT) dst[idx + lo_off] = from_f32<TC>(v - to_f32(hi));
+}
+
+template <typename T, typename TC, bool SPLIT>
 __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, const T* __restrict__ y, int n_total,
                                                        int n_pad, int D, int DPAD, TC* __restrict__ zp,
                                                        TC* __restrict__ yp, float* __restrict__ zn,
                                                        float* __restrict__ yn, float* __restrict__ colpart,
-                                                       int rows_per_wave, int nwaves, int lo, int hi, int nw0, int nw1) {
+                                                       int rows_per_wave, int nwaves, int lo, int hi, int nw0, int nw1,
+                                                       long long lo_off) {
     const int lane = threadIdx.x & 63;
     const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wg >= nwaves) return;
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                     for (int j = 0; j < 4; ++j) {
                         const int c = lane + 64 * j;
                         if (j < NJ && c < DPAD) {
-                            dst[(long long)rr * DPAD + c] = from_f32<TC>(v[u][j]);
+                            prep_store<TC, SPLIT>(dst, (long long)rr * DPAD + c, lo_off, v[u][j]);
                             csum[j] += v[u][j];
                             sq = fmaf(v[u][j], v[u][j], sq);
                         }
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                 const int c = lane + 64 * j;
                 if (j < NJ && c < DPAD) {
                     const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
-                    dst[(long long)row * DPAD + c] = from_f32<TC>(v);    // TC == bf16 only with T == bf16: exact
+                    prep_store<TC, SPLIT>(dst, (long long)row * DPAD + c, lo_off, v);    // TC == bf16 without SPLIT only with T == bf16: exact
                     csum[j] += v;
                     sq = fmaf(v, v, sq);
                 }
@@ -657,7 +666,7 @@ __global__ __launch_bounds__(1024) void mmd_moments_kernel(const float* __restri
 
 struct FinalArgs {
     const double* wg_sums; int nwg0, nwg1;   // nwg0 problem-0 workgroups come first, then nwg1 problem-1 ones
-    const double* wg_rowsum; const float* wg_grad; const float* shift; const void* zp;
+    const double* wg_rowsum; const float* wg_grad; const float* shift; const void* z_src;   // z_src: the caller's z_all (n_total, D)
     int col_splits, n_rows, n_rows_pad, row_offset, D, DPAD;
     double* sums3; float* loss; double loss_scale; double grad_scale;
     void* d_z;
@@ -665,7 +674,7 @@ struct FinalArgs {
     const float* zn; const float* yn; int n_total; const double* dots; int ndots;
 };
 
-template <typename T, typename TC>
+template <typename T>
 __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
     __shared__ double red[3][256];
     const int tid = threadIdx.x;
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
             rsum += f.wg_rowsum[(long long)s * f.n_rows_pad + row];
             gsum += f.wg_grad[((long long)s * f.n_rows_pad + row) * f.DPAD + c];
         }
-        const double zv = (double)to_f32(static_cast<const TC*>(f.zp)[((long long)f.row_offset + row) * f.DPAD + c]);
+        const double zv = (double)to_f32(static_cast<const T*>(f.z_src)[((long long)f.row_offset + row) * f.D + c]);
         const double v = f.grad_scale * (-zv * rsum + (double)f.shift[c] + (double)gsum);
         out[idx] = from_f32<T>((float)v);
     }
@@ -739,7 +748,8 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
 
 // ---- host side ------------------------------------------------------------------------
 struct Plan {
-    int bf16_tiles;   // 1: bf16 copies + mmd_bf16_kernel<KB = DPAD / 128> (bf16 inputs, D > 192)
+    int bf16_tiles;   // 1: bf16 copies + mmd_bf16_kernel<KB = DPAD / 128> (bf16 inputs, or split fp32 inputs, D > 192)
+    int split;        // 1 (with bf16_tiles): fp32 inputs as hi + lo bf16 copies, three products per fp32 product
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
@@ -755,20 +765,32 @@ struct Shape { int dpad, waves, nb; };
 const Shape kShapes[] = {{16, 1, 1}, {32, 1, 2}, {48, 1, 3}, {64, 1, 4}, {80, 1, 5}, {96, 1, 6}, {112, 1, 7},
                          {128, 1, 8}, {160, 1, 10}, {192, 1, 12}, {256, 4, 4}, {384, 4, 6},
                          {512, 4, 8}, {768, 4, 12}, {1024, 8, 8}};
+#ifndef TVAE_SPLIT_RT4_MAX_KB
+#define TVAE_SPLIT_RT4_MAX_KB 6
+#endif
+constexpr int kSplitRt4MaxKb = TVAE_SPLIT_RT4_MAX_KB;    // split gradient launch: 64-row blocks up to this many feature blocks
 const Shape* pick_shape(int64_t D) {
     for (const Shape& sh : kShapes)
         if (sh.dpad >= D) return &sh;
     return nullptr;
 }
 
-// bf16 inputs with a wide latent run on the bf16 matrix cores (narrow ones stay on the single-wave
-// fp32 kernels, whose inputs are widened exactly)
-bool use_bf16_tiles(int dtype, int64_t D) { return dtype == TVAE_BF16 && D > 192 && D <= 1024; }
+// Kernel family of a call.  Wide latents (192 < D <= 1024): bf16 inputs run on the bf16 matrix cores; fp32 inputs run
+// there too, as hi + lo bf16 pairs with three products per fp32 product (MODE_SPLIT, same 1e-5 accuracy class as the
+// fp32-input MFMA at 16x its rate), unless the caller asks for TVAE_F32_STRICT.  Narrow latents stay on the
+// single-wave fp32 kernels (bf16 inputs are widened exactly).
+enum { MODE_F32 = 0, MODE_BF16 = 1, MODE_SPLIT = 2 };
+int mmd_mode(int dtype, int64_t D) {
+    if (D <= 192 || D > 1024) return MODE_F32;
+    return dtype == TVAE_BF16 ? MODE_BF16 : (dtype == TVAE_F32 ? MODE_SPLIT : MODE_F32);
+}
 
-bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool bf16_tiles, Plan* p) {
+bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int mode, Plan* p) {
     const Shape* sh = pick_shape(D);
     if (!sh) return false;
+    const bool bf16_tiles = mode != MODE_F32;
     p->bf16_tiles = bf16_tiles ? 1 : 0;
+    p->split = mode == MODE_SPLIT ? 1 : 0;
     p->NB = sh->nb;
     p->WAVES = sh->waves;
     p->DPAD = sh->dpad;
@@ -788,13 +810,16 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     const int rows_wg = p->narrow64 ? 64 : ROWS_PER_WG;
     p->n_pad = (int)align_up(n_total, rows_wg);      // whole 32- (64-) point blocks (symmetric y-y enumeration)
     p->row_blocks = (int)((n_rows + rows_wg - 1) / rows_wg);
-    p->RT = 2;        // see Bf16Lds: 64-row blocks (RT = 4) lose the second resident workgroup and measured slower
+    // bf16 inputs: 64-row blocks (RT = 4) lose the second resident workgroup and measured slower (see Bf16Lds).
+    // Split fp32 inputs: one workgroup per CU either way (its hi + lo point tile is 96 KiB at D = 768) and three
+    // times the matrix work per byte: 64 rows halve the L2 -> LDS stream.
+    p->RT = (p->split && want_grad && p->NB <= kSplitRt4MaxKb) ? 4 : 2;
     p->row_blocks_g = p->narrow64 ? p->row_blocks : (int)((n_rows + 16 * p->RT - 1) / (16 * p->RT));
     p->n_rows_pad = p->narrow64 ? p->row_blocks * 64 : p->row_blocks_g * 16 * p->RT;
     p->tiles_per_set = p->n_pad / TILE_P;
     // Column splits: enough workgroups to fill the chip, and a count that fills the LAST round of
     // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
-    const int wg_per_cu = bf16_tiles ? ((p->RT == 2 && p->NB <= 6) ? 2 : 1)
+    const int wg_per_cu = bf16_tiles ? ((!p->split && p->RT == 2 && p->NB <= 6) ? 2 : 1)
                                      : (p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1));
     const int slots = 256 * wg_per_cu;
     // at least 32 of the 2 * tiles_per_set column tiles per split (4 when the whole problem is tiny)
@@ -818,7 +843,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     // gradient slab per split (capped at 32 GiB).
     p->sp_major = 0;
     if (bf16_tiles) {
-        const int64_t col_bytes = 2ll * p->n_pad * p->DPAD * 2;
+        const int64_t col_bytes = 2ll * p->n_pad * p->DPAD * (p->split ? 4 : 2);
         if (col_bytes > (64ll << 20)) {
             int64_t want = (col_bytes + (24ll << 20) - 1) / (24ll << 20);
             const int64_t hard_max = p->tiles_per_set / 16 < 64 ? p->tiles_per_set / 16 : 64;   // >= 16 tiles of a set per split
@@ -839,7 +864,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, bool 
     p->nwaves = (p->n_pad + rpw - 1) / rpw + 2;       // upper bound: the row range of a call adds two chunk ends
     int64_t off = 0;
     auto take = [&](int64_t bytes) { int64_t o = off; off = align_up(off + bytes, 256); return o; };
-    const int copy_elt = bf16_tiles ? 2 : 4;
+    const int copy_elt = (bf16_tiles && !p->split) ? 2 : 4;     // split: the hi copy, then the lo copy
     p->off_zp = take((int64_t)p->n_pad * p->DPAD * copy_elt);
     p->off_yp = take((int64_t)p->n_pad * p->DPAD * copy_elt);
     p->off_zn = take((int64_t)p->n_pad * 4);
@@ -933,7 +958,7 @@ int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
 
 template <bool GRAD>
 int launch_tiles(const Plan& p, const MmdArgs& a, int nblocks, hipStream_t s) {
-    if (p.bf16_tiles) return launch_mmd_bf16(GRAD, p.NB, a, nblocks, s);
+    if (p.bf16_tiles) return launch_mmd_bf16(GRAD, p.split != 0, p.NB, GRAD ? p.RT : 2, a, nblocks, s);
     if (p.narrow64) return launch_mmd_narrow(GRAD, p.NB, a, nblocks, s);
     return launch_tile_shape<GRAD>(p.DPAD, a, nblocks, s);
 }
@@ -957,22 +982,22 @@ extern "C" int tvae_profile_next_mmd(void* ev_start, void* ev_stop) {
 
 extern "C" int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad) {
     // the dtype is not an argument here: report the larger of the two plans a call may pick
-    Plan p, q;
-    if (n_total > 0 && n_rows > 0 && D > 1024 && n_total < (1ll << 30))
-        return mmd_wide_workspace_bytes(n_total, n_rows, D, want_grad != 0);
-    if (n_total <= 0 || n_rows <= 0 || D <= 0 || !make_plan(n_total, n_rows, D, want_grad != 0, false, &p)) return -1;
-    if (use_bf16_tiles(TVAE_BF16, D) && make_plan(n_total, n_rows, D, want_grad != 0, true, &q) && q.bytes > p.bytes)
-        return q.bytes;
-    return p.bytes;
+    int64_t best = -1;
+    for (int dtype : {TVAE_F32, TVAE_BF16, TVAE_F32_STRICT}) {
+        const int64_t b = tvae_mmd_workspace_bytes_for(n_total, n_rows, D, want_grad, dtype);
+        if (b < 0) return -1;
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 extern "C" int64_t tvae_mmd_workspace_bytes_for(int64_t n_total, int64_t n_rows, int64_t D, int want_grad, int dtype) {
-    if (dtype != TVAE_F32 && dtype != TVAE_BF16) return -1;
+    if (dtype != TVAE_F32 && dtype != TVAE_BF16 && dtype != TVAE_F32_STRICT) return -1;
     if (n_total > 0 && n_rows > 0 && D > 1024 && n_total < (1ll << 30))
         return mmd_wide_workspace_bytes(n_total, n_rows, D, want_grad != 0);
     Plan p;
     if (n_total <= 0 || n_rows <= 0 || D <= 0 ||
-        !make_plan(n_total, n_rows, D, want_grad != 0, use_bf16_tiles(dtype, D), &p)) return -1;
+        !make_plan(n_total, n_rows, D, want_grad != 0, mmd_mode(dtype, D), &p)) return -1;
     return p.bytes;
 }
 
@@ -983,7 +1008,9 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
                      int64_t workspace_bytes, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     TVAE_REQUIRE(z_all && y_all && sums3 && workspace, "mmd: null pointer argument");
-    TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16, "mmd: unknown dtype %d", dtype);
+    TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16 || dtype == TVAE_F32_STRICT, "mmd: unknown dtype %d", dtype);
+    const int mode = mmd_mode(dtype, D);
+    if (dtype == TVAE_F32_STRICT) dtype = TVAE_F32;          // from here on: the element type of the inputs
     TVAE_REQUIRE(n_total > 0 && n_rows > 0 && D > 0, "mmd: empty problem (n_total=%lld n_rows=%lld D=%lld)",
                  (long long)n_total, (long long)n_rows, (long long)D);
     TVAE_REQUIRE(row_offset >= 0 && row_offset + n_rows <= n_total, "mmd: row block [%lld,%lld) outside [0,%lld)",
@@ -999,7 +1026,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
         return TVAE_OK;
     }
     Plan p;
-    TVAE_REQUIRE(make_plan(n_total, n_rows, D, d_z != nullptr, use_bf16_tiles(dtype, D), &p),
+    TVAE_REQUIRE(make_plan(n_total, n_rows, D, d_z != nullptr, mode, &p),
                  "mmd: latent dimension %lld not supported (max 1024)", (long long)D);
     if (workspace_bytes < p.bytes)
         return fail(TVAE_ERR_WORKSPACE, "mmd: workspace %lld B < required %lld B", (long long)workspace_bytes,
@@ -1019,18 +1046,23 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     const int nw0 = (lo + rpw - 1) / rpw, nw1 = (hi - lo + rpw - 1) / rpw, nw2 = (p.n_pad - hi + rpw - 1) / rpw;
     const int nwaves = nw0 + nw1 + nw2;          // <= p.nwaves (the plan's bound)
     dim3 pgrid((nwaves + 3) / 4, 2);
-    if (dtype == TVAE_F32)
-        hipLaunchKernelGGL((mmd_prep_kernel<float, float>), pgrid, dim3(256), 0, s, (const float*)z_all,
+    const long long lo_off = (long long)p.n_pad * p.DPAD;      // split: elements from the hi copy to the lo copy
+    if (p.split)
+        hipLaunchKernelGGL((mmd_prep_kernel<float, bf16, true>), pgrid, dim3(256), 0, s, (const float*)z_all,
+                           (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (bf16*)zp, (bf16*)yp, zn, yn,
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, lo_off);
+    else if (dtype == TVAE_F32)
+        hipLaunchKernelGGL((mmd_prep_kernel<float, float, false>), pgrid, dim3(256), 0, s, (const float*)z_all,
                            (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll);
     else if (!p.bf16_tiles)
-        hipLaunchKernelGGL((mmd_prep_kernel<bf16, float>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
+        hipLaunchKernelGGL((mmd_prep_kernel<bf16, float, false>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
                            (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll);
     else
-        hipLaunchKernelGGL((mmd_prep_kernel<bf16, bf16>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
+        hipLaunchKernelGGL((mmd_prep_kernel<bf16, bf16, false>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
                            (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (bf16*)zp, (bf16*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll);
     TVAE_CHECK_HIP(hipGetLastError());
     double* dots = reinterpret_cast<double*>(ws + p.off_dots);
     const int ndots = (p.DPAD + 63) / 64;
@@ -1039,6 +1071,11 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
 
     MmdArgs a;
     a.cols[0] = (const float*)zp; a.cols[1] = (const float*)yp; a.cnorm[0] = zn; a.cnorm[1] = yn;
+    a.cols_lo[0] = a.cols_lo[1] = nullptr;
+    if (p.split) {
+        a.cols_lo[0] = reinterpret_cast<const float*>(static_cast<const bf16*>(zp) + lo_off);
+        a.cols_lo[1] = reinterpret_cast<const float*>(static_cast<const bf16*>(yp) + lo_off);
+    }
     a.n_rows = (int)n_rows; a.n_cols = (int)n_total; a.row_offset = (int)row_offset;
     a.row_blocks = p.row_blocks; a.col_splits = p.col_splits; a.tiles_per_set = p.tiles_per_set;
     a.n_rows_pad = p.n_rows_pad;
@@ -1082,7 +1119,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     if (ev1) TVAE_CHECK_HIP(hipEventRecord(ev1, s));
 
     FinalArgs f;
-    f.wg_sums = a.wg_sums; f.nwg0 = nwg0; f.nwg1 = nwg1; f.wg_rowsum = a.wg_rowsum; f.wg_grad = a.wg_grad; f.shift = shift; f.zp = zp;
+    f.wg_sums = a.wg_sums; f.nwg0 = nwg0; f.nwg1 = nwg1; f.wg_rowsum = a.wg_rowsum; f.wg_grad = a.wg_grad; f.shift = shift; f.z_src = z_all;
     f.col_splits = p.col_splits; f.n_rows = (int)n_rows; f.n_rows_pad = p.n_rows_pad; f.row_offset = (int)row_offset;
     f.D = (int)D; f.DPAD = p.DPAD; f.sums3 = sums3; f.loss = loss; f.loss_scale = loss_scale; f.grad_scale = grad_scale;
     f.d_z = d_z;
@@ -1090,9 +1127,8 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
     if (fb > 4096) fb = 4096;
     if (fb < 1) fb = 1;
-    if (dtype == TVAE_F32) hipLaunchKernelGGL((mmd_finalize_kernel<float, float>), dim3((unsigned)fb), dim3(256), 0, s, f);
-    else if (!p.bf16_tiles) hipLaunchKernelGGL((mmd_finalize_kernel<bf16, float>), dim3((unsigned)fb), dim3(256), 0, s, f);
-    else hipLaunchKernelGGL((mmd_finalize_kernel<bf16, bf16>), dim3((unsigned)fb), dim3(256), 0, s, f);
+    if (dtype == TVAE_F32) hipLaunchKernelGGL((mmd_finalize_kernel<float>), dim3((unsigned)fb), dim3(256), 0, s, f);
+    else hipLaunchKernelGGL((mmd_finalize_kernel<bf16>), dim3((unsigned)fb), dim3(256), 0, s, f);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }
@@ -1137,7 +1173,7 @@ int scratch_of_current_device(void** out) {
 extern "C" int tvae_mmd_fwd_bwd_static(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
                                        int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
                                        double loss_scale, void* d_z, double grad_scale, void* stream) {
-    TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16, "mmd_static: unknown dtype %d", dtype);
+    TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16 || dtype == TVAE_F32_STRICT, "mmd_static: unknown dtype %d", dtype);
     const int64_t need = tvae_mmd_workspace_bytes_for(n_total, n_rows, D, d_z != nullptr, dtype);
     TVAE_REQUIRE(need >= 0, "mmd_static: unsupported problem (n_total=%lld n_rows=%lld D=%lld)", (long long)n_total,
                  (long long)n_rows, (long long)D);

@@ -41,30 +41,38 @@ constexpr int STEP_P = 32;
 // traffic per flop, but 434 registers per lane = one wave per SIMD) was measured SLOWER at every width
 // (N = 32768: D = 768 11.3 ms vs 9.05 ms, D = 256 5.06 vs 4.49): with 16-cycle MFMAs the second resident
 // workgroup, which hides the exchange / expm1 / barrier phases, is worth more than the halved traffic.
-template <int KB, int RT, bool GRAD>
+template <int KB, int RT, bool GRAD, bool SPLIT>
 struct Bf16Lds {
     static constexpr int SW = 32 * KB;                       // bf16 features per wave
     static constexpr int TPW = RT / 2;                       // S' tiles finished per wave
-    static constexpr int SLICE_B = STEP_P * SW * 2;          // bytes of one wave's slice of a 32-point step
-    static constexpr int NORM_B = 4 * SLICE_B;               // [2 buf][4 waves][32] float point norms
+    static constexpr int SLICE_B = STEP_P * SW * 2;          // bytes of one wave's slice of a 32-point step (one image)
+    static constexpr int SLICE_W = (SPLIT ? 2 : 1) * SLICE_B;   // SPLIT: the hi image, then the lo image
+    static constexpr int NORM_B = 4 * SLICE_W;               // [2 buf][4 waves][32] float point norms
     static constexpr int XCH_B = NORM_B + 2 * 4 * STEP_P * 4;
     static constexpr int XCH_ONE_B = 2 * RT * 3 * 64 * 16;   // [tile][3 remote sources][64 lanes] float4
     // the gradient instantiation has a second barrier per step, which also protects a single exchange buffer
     static constexpr int XBUFS = GRAD ? 1 : (KB <= 6 ? 2 : 1);
     static constexpr int EBUF_B = XCH_B + XBUFS * XCH_ONE_B; // [RT row tiles][64 lanes][2 point tiles] 4 x bf16
-    static constexpr int BYTES = EBUF_B + (GRAD ? RT * 64 * 16 : 0);
+    static constexpr int EBUF_ONE_B = RT * 64 * 16;          // SPLIT: E_hi, then E_lo
+    static constexpr int BYTES = EBUF_B + (GRAD ? (SPLIT ? 2 : 1) * EBUF_ONE_B : 0);
     // two workgroups per CU when LDS and registers (<= 256 per lane) both allow it
-    static constexpr int WG_PER_CU = (RT == 2 && KB <= 6) ? 2 : 1;
+    static constexpr int WG_PER_CU = (!SPLIT && RT == 2 && KB <= 6) ? 2 : 1;
     static_assert(RT == 2 || RT == 4, "2 or 4 row tiles");
     static_assert(BYTES <= 160 * 1024, "bf16 tile kernel exceeds the 160 KiB LDS");
     static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses the exchange buffer");
 };
 
-template <int KB, int RT, bool GRAD>
-__global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
-    using L = Bf16Lds<KB, RT, GRAD>;
+// SPLIT (fp32 inputs, "three bf16 products per fp32 product"): every fp32 value v is held as hi = bf16(v) and
+// lo = bf16(v - hi) (16 significant bits, relative error 2^-18); the Gram is X_hi Z_hi + X_hi Z_lo + X_lo Z_hi and the
+// gradient product X_hi^T E_hi + X_lo^T E_hi + X_hi^T E_lo, all accumulated in fp32 by the matrix cores.  The dropped
+// lo x lo terms are ~2^-18 of a product, the size of the fp32 MFMA chain's own rounding at these depths.  Everything
+// else (norms, t, expm1, sums, row sums) is the fp32 / fp64 arithmetic of the exact kernel.
+template <int KB, int RT, bool GRAD, bool SPLIT>
+__global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
+    using L = Bf16Lds<KB, RT, GRAD, SPLIT>;
     static_assert(GRAD || RT == 2, "the symmetric y-y enumeration assumes 32-row blocks");
-    constexpr int SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;     // NI: DMA instructions = 16-feature blocks per slice
+    constexpr int SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;     // NI: 16-feature blocks per slice
+    constexpr int DPS = SPLIT ? 4 : 2;                        // DMA instructions per 32-feature block pair
     constexpr int TPW = L::TPW, ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
@@ -72,8 +80,8 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned xs_byte = smem_byte + (unsigned)(wave * L::SLICE_B);
-    const char* xs = sm + wave * L::SLICE_B;
+    const unsigned xs_byte = smem_byte + (unsigned)(wave * L::SLICE_W);
+    const char* xs = sm + wave * L::SLICE_W;
     // the S' tiles this wave finishes: point tile my_pt, row tiles my_t0 .. my_t0 + TPW - 1
     const int my_pt = wave >> 1, my_t0 = (wave & 1) * TPW;
 
@@ -88,15 +96,21 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
     // ---- the rows of this workgroup: this wave's feature slice, in registers as MFMA B operands ----
     const bf16* rows = reinterpret_cast<const bf16*>(a.cols[problem]) + (long long)a.row_offset * DPAD;
     const float* rnorm = a.cnorm[problem] + a.row_offset;
-    bf16x8_t zreg[RT][KB];
+    const bf16* rows_lo = SPLIT ? reinterpret_cast<const bf16*>(a.cols_lo[problem]) + (long long)a.row_offset * DPAD : rows;
+    bf16x8_t zreg[RT][KB], zlo[SPLIT ? RT : 1][SPLIT ? KB : 1];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         const int row = i0 + 16 * t + i16;
         const bf16* zp = rows + (long long)row * DPAD + wave * SW + 8 * g;
+        const bf16* zl = rows_lo + (long long)row * DPAD + wave * SW + 8 * g;
 #pragma unroll
         for (int s = 0; s < KB; ++s) {
             if (row < a.n_rows) zreg[t][s] = *reinterpret_cast<const bf16x8_t*>(zp + 32 * s);
             else zreg[t][s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (SPLIT) {
+                if (row < a.n_rows) zlo[t][s] = *reinterpret_cast<const bf16x8_t*>(zl + 32 * s);
+                else zlo[t][s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
     }
     bool my_valid[TPW];
@@ -112,7 +126,10 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int s = 0; s < KB; ++s) asm volatile("" : "+v"(zreg[t][s]));
+        for (int s = 0; s < KB; ++s) {
+            asm volatile("" : "+v"(zreg[t][s]));
+            if constexpr (SPLIT) asm volatile("" : "+v"(zlo[t][s]));
+        }
 #pragma unroll
     for (int j = 0; j < TPW; ++j) asm volatile("" : "+v"(rn[j]));
     const bool any_invalid = __any(!all_valid);
@@ -154,11 +171,19 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
             (__attribute__((address_space(3))) s16x4_t*)(__attribute__((address_space(3))) char*)(sm + byte_off));
     };
 
-    auto step_src = [&](int v) -> const bf16* {
+    // this wave's slice of step v in the hi (only) copy and, SPLIT, the lo copy
+    struct Src { const bf16* hi; const bf16* lo; };
+    auto step_src = [&](int v) -> Src {
         const int u = actual(v);
         const int set = u >= nJ ? 1 : 0;
+#ifdef TVAE_DEBUG_SAME_TILE
+        const int p0 = 0 * u;                    // experiment: every step streams the same (cache-hot) tile
+#else
         const int p0 = (u - set * nJ) * STEP_P;
-        return reinterpret_cast<const bf16*>(a.cols[set]) + (long long)p0 * DPAD + wave * SW;
+#endif
+        const long long off = (long long)p0 * DPAD + wave * SW;
+        return Src{reinterpret_cast<const bf16*>(a.cols[set]) + off,
+                   SPLIT ? reinterpret_cast<const bf16*>(a.cols_lo[set]) + off : nullptr};
     };
     auto stage_norms = [&](int v, int nbuf) {
         const int u = actual(v);
@@ -170,8 +195,11 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
         if (lane < STEP_P) dma4(src, (unsigned)lane * 4u, dst);
     };
     const unsigned dma_voff_b = dma_voff + 16u * DPAD * 2u - 1024u;      // second point tile, see dma16_pair
-    auto dma_pair = [&](const bf16* X, int s) {       // features [32 s, 32 s + 32) of both point tiles
-        dma16_pair(reinterpret_cast<const float*>(X + 32 * s), dma_voff, dma_voff_b, xs_byte + 2048u * s);
+    auto dma_pair = [&](const Src& X, int s) {       // features [32 s, 32 s + 32) of both point tiles (SPLIT: hi, then lo)
+        dma16_pair(reinterpret_cast<const float*>(X.hi + 32 * s), dma_voff, dma_voff_b, xs_byte + 2048u * s);
+        if constexpr (SPLIT)
+            dma16_pair(reinterpret_cast<const float*>(X.lo + 32 * s), dma_voff, dma_voff_b,
+                       xs_byte + (unsigned)L::SLICE_B + 2048u * s);
     };
 
     double sum0 = 0.0, sum1 = 0.0, rowsum[TPW];
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
     // the counted waits hold on every iteration.
     if (sb < se) {
         stage_norms(sb, 0);
-        const bf16* X0 = step_src(sb);
+        const Src X0 = step_src(sb);
 #pragma unroll
         for (int s = 0; s < KB; ++s) dma_pair(X0, s);
     }
@@ -199,7 +227,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
         const float wsym = (sym && (p0 >> 5) != blkI) ? 2.f : 1.f;
         const int buf = (step - sb) & 1;
         const int nstep = step + 1 < se ? step + 1 : step;
-        const bf16* Xn = step_src(nstep);
+        const Src Xn = step_src(nstep);
         stage_norms(nstep, buf ^ 1);
 
         // 1. partial Gram over the slice: S[pt][t] (16 points x 16 rows each)
@@ -211,27 +239,43 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
 #pragma unroll
         for (int t = 0; t < RT; ++t) S[0][t] = S[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int GD = KB < 2 ? KB : 2;
-        bf16x8_t ab[KB][2];
-        auto gram_wait = [&](int sr, int issued_pairs) { wait_vmcnt_n(NI - 2 * sr - 1 + (GRAD ? 0 : 2 * issued_pairs)); };
+        bf16x8_t ab[KB][2], al[SPLIT ? KB : 1][2];
+        // before the read of k-step sr: all but the younger blocks of this step, norms(k+1) and (sum-only) the
+        // refills already issued may still be in flight
+        auto gram_wait = [&](int sr, int issued_pairs) {
+            wait_vmcnt_n(DPS * (KB - 1 - sr) + 1 + (GRAD ? 0 : DPS * issued_pairs));
+        };
+        auto gram_read = [&](int sr) {
+            ab[sr][0] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * sr);
+            ab[sr][1] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * sr + 1024);
+            if constexpr (SPLIT) {
+                al[sr][0] = *reinterpret_cast<const bf16x8_t*>(xs + L::SLICE_B + gram_off + 2048 * sr);
+                al[sr][1] = *reinterpret_cast<const bf16x8_t*>(xs + L::SLICE_B + gram_off + 2048 * sr + 1024);
+            }
+        };
 #pragma unroll
         for (int s = 0; s < GD; ++s) {
             gram_wait(s, 0);
-            ab[s][0] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * s);
-            ab[s][1] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * s + 1024);
+            gram_read(s);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KB; ++s) {
             if (s + GD < KB) {
                 gram_wait(s + GD, s);
-                ab[s + GD][0] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + GD));
-                ab[s + GD][1] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * (s + GD) + 1024);
+                gram_read(s + GD);
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the reads GD k-steps ahead (hipcc sinks them otherwise)
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 S[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][0], zreg[t][s], S[0][t], 0, 0, 0);
                 S[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][1], zreg[t][s], S[1][t], 0, 0, 0);
+                if constexpr (SPLIT) {
+                    S[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][0], zlo[t][s], S[0][t], 0, 0, 0);
+                    S[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][1], zlo[t][s], S[1][t], 0, 0, 0);
+                    S[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][0], zreg[t][s], S[0][t], 0, 0, 0);
+                    S[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][1], zreg[t][s], S[1][t], 0, 0, 0);
+                }
             }
             if (!GRAD) {
 #pragma unroll
@@ -281,6 +325,12 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
                 sv[j][r] = tt;
                 tmax = fmaxf(tmax, tt);
             }
+#ifdef TVAE_DEBUG_CHEAP_E
+        if (true) {                              // experiment: no expm1 arithmetic
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) { e[j] = sv[j]; q[j] = sv[j]; }
+        } else
+#endif
         if (!__any(tmax >= EM1_TINY)) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j)
@@ -344,23 +394,38 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
                 uint2 ebits = __builtin_bit_cast(uint2, eb);
                 ebits.x ^= flip; ebits.y ^= flip;
                 ebuf[((my_t0 + j) * 64 + lane) * 2 + my_pt] = ebits;
+                if constexpr (SPLIT) {
+                    bf16x4_t el;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) el[r] = (__bf16)(e[j][r] - (float)eb[r]);
+                    uint2 lbits = __builtin_bit_cast(uint2, el);
+                    lbits.x ^= flip; lbits.y ^= flip;
+                    ebuf[(L::EBUF_ONE_B / 8) + ((my_t0 + j) * 64 + lane) * 2 + my_pt] = lbits;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PHASE_MARK(2);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             PHASE_MARK(3);
-            bf16x8_t Eb[RT];
+            bf16x8_t Eb[RT], El[SPLIT ? RT : 1];
 #pragma unroll
-            for (int t = 0; t < RT; ++t) Eb[t] = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (t * 64 + lane) * 16);
-            const int tb0 = wave * L::SLICE_B + tr_off0, tb1 = wave * L::SLICE_B + tr_off1;
+            for (int t = 0; t < RT; ++t) {
+                Eb[t] = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (t * 64 + lane) * 16);
+                if constexpr (SPLIT) El[t] = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + L::EBUF_ONE_B + (t * 64 + lane) * 16);
+            }
+            const int tb0 = wave * L::SLICE_W + tr_off0, tb1 = wave * L::SLICE_W + tr_off1;
             // transposed operand reads run TD blocks ahead of their MFMAs
-            constexpr int TD = NI < 3 ? NI : 3;
-            s16x4_t ga[NI][2];
+            constexpr int TD = NI < 3 ? NI : (SPLIT ? 2 : 3);
+            s16x4_t ga[NI][2], gl[SPLIT ? NI : 1][2];
             auto grad_read = [&](int db) {
                 const int nb = ((db & 1) ? tb1 : tb0) + 2048 * (db >> 1);
                 ga[db][0] = tr_read(nb);
                 ga[db][1] = tr_read(nb + 1024);
+                if constexpr (SPLIT) {
+                    gl[db][0] = tr_read(nb + L::SLICE_B);
+                    gl[db][1] = tr_read(nb + L::SLICE_B + 1024);
+                }
             };
 #pragma unroll
             for (int db = 0; db < TD; ++db) grad_read(db);
@@ -374,6 +439,15 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD>::WG_PER_CU)) void mmd_b
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
                     acc[db][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab2, Eb[t], acc[db][t], 0, 0, 0);
+                if constexpr (SPLIT) {
+                    const s16x8_t lv = __builtin_shufflevector(gl[db][0], gl[db][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8_t al2 = __builtin_bit_cast(bf16x8_t, lv);
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        acc[db][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab2, El[t], acc[db][t], 0, 0, 0);
+                        acc[db][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al2, Eb[t], acc[db][t], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(acc[db][t]));
                 // features [32 s, 32 s + 32) of the step are dead after block 2 s + 1 -> refill both point tiles
@@ -440,37 +514,53 @@ constexpr int kDebugLdsPadMax = 0;
 constexpr int debug_lds_pad() { return 0; }
 #endif
 
-template <int KB, int RT, bool GRAD>
+template <int KB, int RT, bool GRAD, bool SPLIT>
 int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
-    constexpr int lds_bytes = Bf16Lds<KB, RT, GRAD>::BYTES;
+    constexpr int lds_bytes = Bf16Lds<KB, RT, GRAD, SPLIT>::BYTES;
+    constexpr int lds_attr = lds_bytes + kDebugLdsPadMax > 160 * 1024 ? 160 * 1024 : lds_bytes + kDebugLdsPadMax;
     static PerDeviceOnce once;
     TVAE_CHECK_HIP(per_device_once(once, [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes + kDebugLdsPadMax);
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD, SPLIT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
     }));
-    hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD>), dim3(nblocks), dim3(256), lds_bytes + debug_lds_pad(), s, a);
+    const int lds_launch = lds_bytes + debug_lds_pad() > lds_attr ? lds_attr : lds_bytes + debug_lds_pad();
+    hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD, SPLIT>), dim3(nblocks), dim3(256), lds_launch, s, a);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }
 
-template <bool GRAD>
-int launch_bf16_shape(int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
+template <bool GRAD, bool SPLIT>
+int launch_bf16_shape(int kb, int rt, const MmdArgs& a, int nblocks, hipStream_t s) {
+    if constexpr (GRAD && SPLIT) {
+        if (rt == 4) {
+            switch (kb) {
+                case 2: return launch_bf16<2, 4, GRAD, SPLIT>(a, nblocks, s);
+                case 3: return launch_bf16<3, 4, GRAD, SPLIT>(a, nblocks, s);
+                case 4: return launch_bf16<4, 4, GRAD, SPLIT>(a, nblocks, s);
+                case 5: return launch_bf16<5, 4, GRAD, SPLIT>(a, nblocks, s);
+                case 6: return launch_bf16<6, 4, GRAD, SPLIT>(a, nblocks, s);
+            }
+            return fail(TVAE_ERR_ARG, "mmd: no 64-row split kernel for %d feature blocks", kb);
+        }
+    }
+    if (rt != 2) return fail(TVAE_ERR_ARG, "mmd: no bf16 kernel with %d row tiles", rt);
     switch (kb) {
-        case 2: return launch_bf16<2, 2, GRAD>(a, nblocks, s);
-        case 3: return launch_bf16<3, 2, GRAD>(a, nblocks, s);
-        case 4: return launch_bf16<4, 2, GRAD>(a, nblocks, s);
-        case 5: return launch_bf16<5, 2, GRAD>(a, nblocks, s);
-        case 6: return launch_bf16<6, 2, GRAD>(a, nblocks, s);
-        case 7: return launch_bf16<7, 2, GRAD>(a, nblocks, s);
-        case 8: return launch_bf16<8, 2, GRAD>(a, nblocks, s);
+        case 2: return launch_bf16<2, 2, GRAD, SPLIT>(a, nblocks, s);
+        case 3: return launch_bf16<3, 2, GRAD, SPLIT>(a, nblocks, s);
+        case 4: return launch_bf16<4, 2, GRAD, SPLIT>(a, nblocks, s);
+        case 5: return launch_bf16<5, 2, GRAD, SPLIT>(a, nblocks, s);
+        case 6: return launch_bf16<6, 2, GRAD, SPLIT>(a, nblocks, s);
+        case 7: return launch_bf16<7, 2, GRAD, SPLIT>(a, nblocks, s);
+        case 8: return launch_bf16<8, 2, GRAD, SPLIT>(a, nblocks, s);
     }
     return fail(TVAE_ERR_ARG, "mmd: no bf16 kernel for %d feature blocks", kb);
 }
 
 }  // namespace
 
-int launch_mmd_bf16(bool grad, int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
-    return grad ? launch_bf16_shape<true>(kb, a, nblocks, s) : launch_bf16_shape<false>(kb, a, nblocks, s);
+int launch_mmd_bf16(bool grad, bool split, int kb, int rt, const MmdArgs& a, int nblocks, hipStream_t s) {
+    if (split) return grad ? launch_bf16_shape<true, true>(kb, rt, a, nblocks, s) : launch_bf16_shape<false, true>(kb, rt, a, nblocks, s);
+    return grad ? launch_bf16_shape<true, false>(kb, rt, a, nblocks, s) : launch_bf16_shape<false, false>(kb, rt, a, nblocks, s);
 }
 
 }  // namespace tvae

@@ -9,6 +9,7 @@ constexpr int TILE_P = 16;
 
 struct MmdArgs {
     const float* cols[2];    // padded fp32 copies: [0] = z_all, [1] = y_all, row stride DPAD
+    const float* cols_lo[2]; // split-bf16 kernels: the lo copies (cols[] are then the hi copies); else unused
     const float* cnorm[2];   // squared norms (0 for padding rows)
     int n_rows, n_cols, row_offset;
     int row_blocks, col_splits, tiles_per_set, n_rows_pad;
@@ -124,7 +125,9 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 #endif
 
 // bf16 matrix-core tile kernels (mmd_bf16.hip); kb = padded dimension / 128 (2..8)
-int launch_mmd_bf16(bool grad, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
+// split: fp32 values as hi + lo bf16 pairs, three products per fp32 product; rt = 16-row tiles per workgroup (2, or 4
+// for the split gradient launch with kb <= 6)
+int launch_mmd_bf16(bool grad, bool split, int kb, int rt, const MmdArgs& a, int nblocks, hipStream_t s);
 // fp32 kernel for narrow latents, 64 rows per single-wave workgroup (mmd_narrow.hip); nb = padded dimension / 16 (1..5)
 int launch_mmd_narrow(bool grad, int nb, const MmdArgs& a, int nblocks, hipStream_t s);
 
