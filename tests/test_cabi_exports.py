@@ -40,10 +40,13 @@ def test_version_and_workspace_queries(lib):
     big = lib.tvae_mmd_workspace_bytes(245760, 245760, 768, 1)
     shard = lib.tvae_mmd_workspace_bytes(245760, 30720, 768, 1)
     assert 0 < small < shard <= big
-    # the dtype-aware query: fp32 needs a few GiB at cfg4; bf16 adds one gradient slab per column chunk (<= 32 GiB)
+    # the dtype-aware query: the fp32-input kernels need a few GiB at cfg4; the matrix-core modes (bf16 inputs, and fp32
+    # inputs as split fp16 pairs) add one gradient slab per column chunk (<= 32 GiB)
     f32 = lib.tvae_mmd_workspace_bytes_for(245760, 245760, 768, 1, 0)
     b16 = lib.tvae_mmd_workspace_bytes_for(245760, 245760, 768, 1, 1)
-    assert 0 < f32 < 8 * 2 ** 30 and f32 <= big and 0 < b16 <= big < 40 * 2 ** 30
+    strict = lib.tvae_mmd_workspace_bytes_for(245760, 245760, 768, 1, 2)
+    assert 0 < strict < 8 * 2 ** 30 and strict <= big and 0 < b16 <= big < 40 * 2 ** 30 and 0 < f32 <= big
+    assert lib.tvae_mmd_workspace_bytes_for(245760, 245760, 768, 1, 3) == -1
     assert lib.tvae_mmd_workspace_bytes_for(350, 350, 77, 1, 7) == -1
     assert lib.tvae_mmd_workspace_bytes(350, 350, 77, 0) <= small
     assert lib.tvae_mmd_workspace_bytes(100, 100, 5000, 1) > 0         # latent_size > 1024: strip-wise route

@@ -93,10 +93,12 @@ def test_cfg3_whole_step_full_size():
     _whole_step(1024, 237, 768, 5, 77, 3, 20243, 48)
 
 
-def test_graph_replay_with_the_soft_rendezvous_on():
-    """A captured MMD call at a size where the gradient launch runs its per-XCD soft rendezvous (arrival counters
-    zeroed by a memset node inside the graph; N = 32 768, D = 768: three epochs): replays with new contents must
-    reproduce the eager results bit for bit, twice in a row."""
+@pytest.mark.parametrize("strict", [True, False])
+def test_graph_replay_of_a_large_mmd_call(strict):
+    """A captured MMD call at N = 32 768, D = 768.  strict: the fp32-input kernel, whose gradient launch runs its
+    per-XCD soft rendezvous at this size (arrival counters zeroed by a memset node inside the graph, three epochs).
+    Default: the split-fp16 kernels, whose operand scale is recomputed from the inputs on every replay.  Replays with
+    new contents must reproduce the eager results bit for bit, three times in a row."""
     import transformer_vae_amd as amd
     from transformer_vae_amd import functional as F
     N, D = 32768, 768
@@ -109,17 +111,17 @@ def test_graph_replay_with_the_soft_rendezvous_on():
     z_buf.requires_grad_(True)
 
     def step(z, y):
-        loss = F.mmd_reg_loss(z, y, batch_size=1, n_latents=1)
+        loss = F.mmd_reg_loss(z, y, batch_size=1, n_latents=1, strict_fp32=strict)
         loss.backward()
         return loss
 
     gs = amd.GraphedStep(step, (z_buf, y_buf), zero_grads=[z_buf])
-    for _ in range(2):
+    for _ in range(3):
         z_new, y_new = draw()
         loss = gs(z_new, y_new)
         torch.cuda.synchronize()
         zt = z_new.clone().requires_grad_(True)
-        want = F.mmd_reg_loss(zt, y_new, batch_size=1, n_latents=1)
+        want = F.mmd_reg_loss(zt, y_new, batch_size=1, n_latents=1, strict_fp32=strict)
         want.backward()
         torch.cuda.synchronize()
         assert torch.equal(loss.detach(), want.detach())

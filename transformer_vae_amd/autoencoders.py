@@ -123,7 +123,16 @@ class EncoderDecoderVAE(nn.Module):
     batch_size = None
 
     def __init__(self, encoder, decoder, use_reg_loss=True, mmd_scope="local", process_group=None,
-                 compensate_ddp_mean=False, mmd_dtype=None):
+                 compensate_ddp_mean=None, mmd_dtype=None, mmd_strict_fp32=False):
+        """``encoder, decoder, use_reg_loss`` as the reference (autoencoders.py:88-92).  Additions:
+
+        ``mmd_scope="global"`` + ``process_group``: one MMD over the batch of all ranks, row-sharded.
+        ``compensate_ddp_mean`` (default: True with global scope): DistributedDataParallel AVERAGES parameter gradients
+        over the R ranks while each rank holds only its rows' share of the global loss gradient; the local latent
+        gradient is multiplied by R so that the averaged result equals the single-process global-batch gradient.
+        Pass False only when gradients are summed, not averaged, across ranks.
+        ``mmd_strict_fp32``: fp32 latents on the fp32-input matrix instruction instead of the default three fp16
+        matrix-core products per fp32 product (same 1e-5 accuracy class, several times faster)."""
         super().__init__()
         if mmd_scope not in ("local", "global"):
             raise ValueError(f"mmd_scope must be 'local' or 'global', got {mmd_scope!r}")
@@ -138,7 +147,9 @@ class EncoderDecoderVAE(nn.Module):
         self.use_reg_loss = use_reg_loss
         self.mmd_scope = mmd_scope
         self.process_group = process_group
-        self.compensate_ddp_mean = compensate_ddp_mean
+        self.compensate_ddp_mean = (mmd_scope == "global") if compensate_ddp_mean is None else bool(compensate_ddp_mean)
+        self.mmd_strict_fp32 = bool(mmd_strict_fp32)
+        self._prior_generators = {}
         # encode -> MMD -> decode as one autograd node when the stock pair is used plainly (same kernels and
         # numbers; less Python autograd bookkeeping per eager step).  False keeps the three separate nodes.
         self.fuse_step = True
@@ -162,10 +173,8 @@ class EncoderDecoderVAE(nn.Module):
                 return False
         if any(p.dtype != h.dtype for p in self.parameters()):
             return False
-        if self.mmd_scope == "global":
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
-                return False
+        if self._global_scope_active():
+            return False
         return True
 
     def _fused_forward(self, h, true_samples):
@@ -173,7 +182,7 @@ class EncoderDecoderVAE(nn.Module):
         n_eff = min(int(enc.n_tokens), h.shape[1])
         L = enc.token_to_latent.weight.shape[0]
         if true_samples is None:
-            true_samples = torch.randn((h.shape[0] * n_eff, L), device=h.device)   # fp32, as the reference (:135)
+            true_samples = self._draw_prior((h.shape[0] * n_eff, L), h.device)     # fp32, as the reference (:135)
         else:
             true_samples = true_samples.reshape(h.shape[0] * n_eff, L).to(h.device)
         w, b = dec._linear_params()
@@ -181,7 +190,7 @@ class EncoderDecoderVAE(nn.Module):
         latent, recon, reg_loss = F.bottleneck_step(
             h, enc.token_to_latent.weight, enc.token_to_latent.bias, w, b,
             None if norm is None else norm.weight, None if norm is None else norm.bias, true_samples,
-            enc.n_tokens, 1e-5 if norm is None else norm.eps)
+            enc.n_tokens, 1e-5 if norm is None else norm.eps, self.mmd_strict_fp32)
         return BaseVAE_Output(latent=latent, reconstructed_encoding=recon, reg_loss=reg_loss)
 
     def _model_forward(self, encoding, latent=None):
@@ -208,26 +217,53 @@ class EncoderDecoderVAE(nn.Module):
     def _compute_mmd(self, x, y):
         """MMD(x = prior samples, y = latents), unscaled (autoencoders.py:128-132); differentiable in y."""
         n, dim = y.shape
-        loss, _ = F.mmd_row_block(y, y, x, 0, 1.0 / float(n) ** 2, 4.0 / (float(n) ** 2 * float(dim) ** 2))
+        loss, _ = F.mmd_row_block(y, y, x, 0, 1.0 / float(n) ** 2, 4.0 / (float(n) ** 2 * float(dim) ** 2),
+                                  self.mmd_strict_fp32)
         return loss
 
-    def _regularliser_loss(self, latent, batch_size, n_latents_per_batch, true_samples=None):
-        """MMD(prior, latent) / batch_size * n_latents (autoencoders.py:112, 134-136).
+    def _global_scope_active(self):
+        if self.mmd_scope != "global":
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
 
-        The 1/batch * n scaling is folded into the kernel's output scale."""
+    def _draw_prior(self, size, device):
+        """``torch.randn(latent.size())`` as the reference (:135), fp32 on the latent's device.
+
+        Global scope: the reference launcher seeds every rank alike (train.py:391), so the default generator would hand
+        every rank the SAME block and the gathered prior would be R copies of it.  Each rank therefore draws from its
+        own stream, seeded ``torch.initial_seed() + 1 + rank`` (kept per device, advanced by every draw)."""
+        if not self._global_scope_active():
+            return torch.randn(size, device=device)
+        import torch.distributed as dist
+        key = str(device)
+        gen = self._prior_generators.get(key)
+        if gen is None:
+            gen = torch.Generator(device=device)
+            gen.manual_seed(torch.initial_seed() + 1 + dist.get_rank(self.process_group))
+            self._prior_generators[key] = gen
+        return torch.randn(size, device=device, generator=gen)
+
+    def _regularliser_loss(self, latent, batch_size=None, n_latents_per_batch=None, true_samples=None):
+        """The reference's one-argument form, ``_regularliser_loss(latent)`` (autoencoders.py:134-136), returns the
+        unscaled MMD(prior, latent).  With ``batch_size`` and ``n_latents_per_batch`` the result is
+        MMD / batch_size * n_latents (:112) -- the scaling folded into the kernel's output scale, which is how
+        ``forward`` calls it."""
         if true_samples is None:
-            true_samples = torch.randn(latent.size(), device=latent.device)   # fp32, as the reference (:135)
+            true_samples = self._draw_prior(latent.size(), latent.device)
         else:
             true_samples = true_samples.reshape(latent.shape).to(latent.device)
+        if batch_size is None or n_latents_per_batch is None:
+            if latent.numel() == 0:
+                return torch.full((), float("nan"), dtype=torch.float32, device=latent.device)
+            return self._compute_mmd(true_samples, latent)
         if latent.numel() == 0:
             # the reference takes the mean of empty kernel matrices (:130-131): nan, not an error
             return torch.full((), float("nan"), dtype=torch.float32, device=latent.device)
         if self.mmd_dtype is not None:
             latent, true_samples = latent.to(self.mmd_dtype), true_samples.to(self.mmd_dtype)
-        if self.mmd_scope == "global":
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
-                from .distributed import sharded_mmd_reg_loss
-                return sharded_mmd_reg_loss(latent, true_samples, batch_size, n_latents_per_batch, self.process_group,
-                                            self.compensate_ddp_mean)
-        return F.mmd_reg_loss(latent, true_samples, batch_size, n_latents_per_batch)
+        if self._global_scope_active():
+            from .distributed import sharded_mmd_reg_loss
+            return sharded_mmd_reg_loss(latent, true_samples, batch_size, n_latents_per_batch, self.process_group,
+                                        self.compensate_ddp_mean, strict_fp32=self.mmd_strict_fp32)
+        return F.mmd_reg_loss(latent, true_samples, batch_size, n_latents_per_batch, self.mmd_strict_fp32)

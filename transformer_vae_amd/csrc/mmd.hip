@@ -531,12 +531,48 @@ __global__ __launch_bounds__(64, 2) void mmd_tile_both_kernel(MmdArgs a, int nwg
 
 // ---- prep: zero-padded copies (row stride DPAD; fp32, or bf16 for the bf16 kernels), squared norms,
 //      per-wave column sums ----
-// SPLIT (TC = bf16, T = float): dst holds hi = bf16(v), and dst + lo_off holds lo = bf16(v - hi)
+// SPLIT (TC = fp16, T = float): dst holds hi = fp16(s v), and dst + lo_off holds lo = fp16(s v - hi) (split_scales)
 template <typename TC, bool SPLIT>
-__device__ __forceinline__ void prep_store(TC* dst, long long idx, long long lo_off, float v) {
-    const TC hi = from_f32<TC>(v);
-    dst[idx] = hi;
-    if constexpr (SPLIT) dst[idx + lo_off] = from_f32<TC>(v - to_f32(hi));
+__device__ __forceinline__ void prep_store(TC* dst, long long idx, long long lo_off, float v, float scale) {
+    if constexpr (SPLIT) {
+        const float sv = v * scale;
+        const TC hi = from_f32<TC>(sv);
+        dst[idx] = hi;
+        dst[idx + lo_off] = from_f32<TC>(sv - to_f32(hi));
+    } else {
+        dst[idx] = from_f32<TC>(v);
+    }
+}
+
+// max |value| over both inputs (split kernels' scale), in two plain-store stages: per-block maxima, then one block
+// reduces them -- no atomics and no word that has to start at zero, so nothing depends on a memset node
+constexpr int AMAX_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void mmd_amax_kernel(const float* __restrict__ z, const float* __restrict__ y, long long count,
+                                                       long long n4, float* __restrict__ part) {
+    __shared__ float red[4];
+    float m = 0.f;      // n4: float4 groups read 16 B at a time (0 for unaligned views); the rest element-wise
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(z)[i], b = reinterpret_cast<const float4*>(y)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256)
+        m = fmaxf(m, fmaxf(fabsf(z[i]), fabsf(y[i])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void mmd_amax_final_kernel(const float* __restrict__ part, int nparts, unsigned* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
 template <typename T, typename TC, bool SPLIT>
@@ -545,7 +581,8 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                                                        TC* __restrict__ yp, float* __restrict__ zn,
                                                        float* __restrict__ yn, float* __restrict__ colpart,
                                                        int rows_per_wave, int nwaves, int lo, int hi, int nw0, int nw1,
-                                                       long long lo_off) {
+                                                       long long lo_off, const unsigned* __restrict__ split_amax) {
+    const float scale = SPLIT ? split_scales(*split_amax).s : 1.f;
     const int lane = threadIdx.x & 63;
     const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wg >= nwaves) return;
@@ -589,7 +626,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                     for (int j = 0; j < 4; ++j) {
                         const int c = lane + 64 * j;
                         if (j < NJ && c < DPAD) {
-                            prep_store<TC, SPLIT>(dst, (long long)rr * DPAD + c, lo_off, v[u][j]);
+                            prep_store<TC, SPLIT>(dst, (long long)rr * DPAD + c, lo_off, v[u][j], scale);
                             csum[j] += v[u][j];
                             sq = fmaf(v[u][j], v[u][j], sq);
                         }
@@ -607,7 +644,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                 const int c = lane + 64 * j;
                 if (j < NJ && c < DPAD) {
                     const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
-                    prep_store<TC, SPLIT>(dst, (long long)row * DPAD + c, lo_off, v);    // TC == bf16 without SPLIT only with T == bf16: exact
+                    prep_store<TC, SPLIT>(dst, (long long)row * DPAD + c, lo_off, v, scale);    // TC == bf16 without SPLIT only with T == bf16: exact
                     csum[j] += v;
                     sq = fmaf(v, v, sq);
                 }
@@ -670,6 +707,7 @@ struct FinalArgs {
     int col_splits, n_rows, n_rows_pad, row_offset, D, DPAD;
     double* sums3; float* loss; double loss_scale; double grad_scale;
     void* d_z;
+    const unsigned* split_amax;   // split kernels: the gradient slabs carry 2^12 s G (split_scales); else null
     // closed-form linear part: squared norms of all points, the local rows, the column-moment dot products
     const float* zn; const float* yn; int n_total; const double* dots; int ndots;
 };
@@ -740,6 +778,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
             rsum += f.wg_rowsum[(long long)s * f.n_rows_pad + row];
             gsum += f.wg_grad[((long long)s * f.n_rows_pad + row) * f.DPAD + c];
         }
+        if (f.split_amax) gsum *= split_scales(*f.split_amax).grad_unscale;       // a power of two: exact
         const double zv = (double)to_f32(static_cast<const T*>(f.z_src)[((long long)f.row_offset + row) * f.D + c]);
         const double v = f.grad_scale * (-zv * rsum + (double)f.shift[c] + (double)gsum);
         out[idx] = from_f32<T>((float)v);
@@ -755,7 +794,7 @@ struct Plan {
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
     int sp_major;     // 1: split-major workgroup order (see make_plan)
     int sync_epochs, sync_group, sync_groups;   // soft rendezvous of the gradient launch (sync_epochs == 0: off)
-    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, off_sync, bytes;
+    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, off_sync, off_amax, bytes;
 };
 
 // (padded dimension, waves per workgroup, 16-column blocks per wave); DPAD = WAVES * 16 * NB
@@ -887,6 +926,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     if (getenv("TVAE_DEBUG_NO_SYNC")) p->sync_epochs = 0;          // experiments only
 #endif
     p->off_sync = take((int64_t)p->sync_groups * 8 * p->sync_epochs * 4);
+    p->off_amax = take(p->split ? 256 + AMAX_BLOCKS * 4 : 0);      // the scale word, then the per-block maxima
     p->bytes = off;
     return true;
 }
@@ -1047,22 +1087,34 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     const int nwaves = nw0 + nw1 + nw2;          // <= p.nwaves (the plan's bound)
     dim3 pgrid((nwaves + 3) / 4, 2);
     const long long lo_off = (long long)p.n_pad * p.DPAD;      // split: elements from the hi copy to the lo copy
-    if (p.split)
-        hipLaunchKernelGGL((mmd_prep_kernel<float, bf16, true>), pgrid, dim3(256), 0, s, (const float*)z_all,
-                           (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (bf16*)zp, (bf16*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, lo_off);
+    unsigned* split_amax = p.split ? reinterpret_cast<unsigned*>(ws + p.off_amax) : nullptr;
+    if (p.split) {
+        const long long count = (long long)n_total * D;
+        long long ab = (count / 4 + 255) / 256;
+        ab = ab < 1 ? 1 : (ab > AMAX_BLOCKS ? AMAX_BLOCKS : ab);
+        const long long n4 = (aligned16(z_all) && aligned16(y_all)) ? count / 4 : 0;
+        float* amax_part = reinterpret_cast<float*>(ws + p.off_amax + 256);
+        hipLaunchKernelGGL(mmd_amax_kernel, dim3((unsigned)ab), dim3(256), 0, s, (const float*)z_all, (const float*)y_all,
+                           count, n4, amax_part);
+        TVAE_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mmd_amax_final_kernel, dim3(1), dim3(256), 0, s, (const float*)amax_part, (int)ab, split_amax);
+        TVAE_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL((mmd_prep_kernel<float, _Float16, true>), pgrid, dim3(256), 0, s, (const float*)z_all,
+                           (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (_Float16*)zp, (_Float16*)yp, zn, yn,
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, lo_off, split_amax);
+    }
     else if (dtype == TVAE_F32)
         hipLaunchKernelGGL((mmd_prep_kernel<float, float, false>), pgrid, dim3(256), 0, s, (const float*)z_all,
                            (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr);
     else if (!p.bf16_tiles)
         hipLaunchKernelGGL((mmd_prep_kernel<bf16, float, false>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
                            (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr);
     else
         hipLaunchKernelGGL((mmd_prep_kernel<bf16, bf16, false>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
                            (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (bf16*)zp, (bf16*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr);
     TVAE_CHECK_HIP(hipGetLastError());
     double* dots = reinterpret_cast<double*>(ws + p.off_dots);
     const int ndots = (p.DPAD + 63) / 64;
@@ -1072,6 +1124,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     MmdArgs a;
     a.cols[0] = (const float*)zp; a.cols[1] = (const float*)yp; a.cnorm[0] = zn; a.cnorm[1] = yn;
     a.cols_lo[0] = a.cols_lo[1] = nullptr;
+    a.split_amax = split_amax;
     if (p.split) {
         a.cols_lo[0] = reinterpret_cast<const float*>(static_cast<const bf16*>(zp) + lo_off);
         a.cols_lo[1] = reinterpret_cast<const float*>(static_cast<const bf16*>(yp) + lo_off);
@@ -1123,6 +1176,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     f.col_splits = p.col_splits; f.n_rows = (int)n_rows; f.n_rows_pad = p.n_rows_pad; f.row_offset = (int)row_offset;
     f.D = (int)D; f.DPAD = p.DPAD; f.sums3 = sums3; f.loss = loss; f.loss_scale = loss_scale; f.grad_scale = grad_scale;
     f.d_z = d_z;
+    f.split_amax = split_amax;
     f.zn = zn; f.yn = yn; f.n_total = (int)n_total; f.dots = dots; f.ndots = ndots;
     long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
     if (fb > 4096) fb = 4096;

@@ -30,6 +30,17 @@ namespace {
 // Sums and row sums use the fp32 E; only the gradient product sees the bf16 rounding of E (2^-9).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+
+// 16x16x32 matrix instruction on 16-bit operands held in a bf16x8_t container: bf16, or (F16) the same bits read as fp16
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x4& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
@@ -62,11 +73,13 @@ struct Bf16Lds {
     static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses the exchange buffer");
 };
 
-// SPLIT (fp32 inputs, "three bf16 products per fp32 product"): every fp32 value v is held as hi = bf16(v) and
-// lo = bf16(v - hi) (16 significant bits, relative error 2^-18); the Gram is X_hi Z_hi + X_hi Z_lo + X_lo Z_hi and the
-// gradient product X_hi^T E_hi + X_lo^T E_hi + X_hi^T E_lo, all accumulated in fp32 by the matrix cores.  The dropped
-// lo x lo terms are ~2^-18 of a product, the size of the fp32 MFMA chain's own rounding at these depths.  Everything
-// else (norms, t, expm1, sums, row sums) is the fp32 / fp64 arithmetic of the exact kernel.
+// SPLIT (fp32 inputs, "three fp16 products per fp32 product"): every fp32 value v is held as hi = fp16(s v) and
+// lo = fp16(s v - hi), s a power of two that puts the largest |v| of the call at 2^11 (22 significant bits, error
+// <= 2^-22 of the largest value: the fp32 input MFMA's own class).  The Gram is X_hi Z_hi + X_hi Z_lo + X_lo Z_hi and
+// the gradient product X_hi^T E_hi + X_lo^T E_hi + X_hi^T E_lo (E in (-1, 0] scaled by 2^12), all accumulated in fp32
+// by the matrix cores; the dropped lo x lo terms are 2^-22 of a product.  A first version on bf16 halves (16 bits)
+// failed the 1e-5 bar on the gradient when the kernel values are O(1) (far-apart points: 1.003e-5).  Everything else
+// (norms, t, expm1, sums, row sums) is the fp32 / fp64 arithmetic of the exact kernel; the scale is undone exactly.
 template <int KB, int RT, bool GRAD, bool SPLIT>
 __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
     using L = Bf16Lds<KB, RT, GRAD, SPLIT>;
@@ -113,6 +126,8 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
             }
         }
     }
+    // SPLIT: the Gram was formed on operands scaled by s (a power of two): 2 S = (2 / s^2) S'
+    const float gram_unscale2 = SPLIT ? 2.f * split_scales(*a.split_amax).inv_s2 : 2.f;
     bool my_valid[TPW];
     float rn[TPW];
     bool all_valid = true;
@@ -268,13 +283,13 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
             __builtin_amdgcn_sched_barrier(0);      // keep the reads GD k-steps ahead (hipcc sinks them otherwise)
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-                S[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][0], zreg[t][s], S[0][t], 0, 0, 0);
-                S[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][1], zreg[t][s], S[1][t], 0, 0, 0);
+                S[0][t] = mfma16<SPLIT>(ab[s][0], zreg[t][s], S[0][t]);
+                S[1][t] = mfma16<SPLIT>(ab[s][1], zreg[t][s], S[1][t]);
                 if constexpr (SPLIT) {
-                    S[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][0], zlo[t][s], S[0][t], 0, 0, 0);
-                    S[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s][1], zlo[t][s], S[1][t], 0, 0, 0);
-                    S[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][0], zreg[t][s], S[0][t], 0, 0, 0);
-                    S[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][1], zreg[t][s], S[1][t], 0, 0, 0);
+                    S[0][t] = mfma16<SPLIT>(ab[s][0], zlo[t][s], S[0][t]);
+                    S[1][t] = mfma16<SPLIT>(ab[s][1], zlo[t][s], S[1][t]);
+                    S[0][t] = mfma16<SPLIT>(al[s][0], zreg[t][s], S[0][t]);
+                    S[1][t] = mfma16<SPLIT>(al[s][1], zreg[t][s], S[1][t]);
                 }
             }
             if (!GRAD) {
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
         for (int j = 0; j < TPW; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float tt = fmaxf((cn[r] + rn[j] - 2.f * sv[j][r]) * a.inv_d2, 0.f);
+                const float tt = fmaxf((cn[r] + rn[j] - gram_unscale2 * sv[j][r]) * a.inv_d2, 0.f);
                 sv[j][r] = tt;
                 tmax = fmaxf(tmax, tt);
             }
@@ -388,19 +403,26 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
             const unsigned flip = set ? 0x80008000u : 0u;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-                bf16x4_t eb;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) eb[r] = (__bf16)e[j][r];
-                uint2 ebits = __builtin_bit_cast(uint2, eb);
-                ebits.x ^= flip; ebits.y ^= flip;
-                ebuf[((my_t0 + j) * 64 + lane) * 2 + my_pt] = ebits;
                 if constexpr (SPLIT) {
-                    bf16x4_t el;
+                    f16x4_t eh, el;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) el[r] = (__bf16)(e[j][r] - (float)eb[r]);
-                    uint2 lbits = __builtin_bit_cast(uint2, el);
+                    for (int r = 0; r < 4; ++r) {
+                        const float es = e[j][r] * SPLIT_E_SCALE;
+                        eh[r] = (_Float16)es;
+                        el[r] = (_Float16)(es - (float)eh[r]);
+                    }
+                    uint2 hbits = __builtin_bit_cast(uint2, eh), lbits = __builtin_bit_cast(uint2, el);
+                    hbits.x ^= flip; hbits.y ^= flip;
                     lbits.x ^= flip; lbits.y ^= flip;
+                    ebuf[((my_t0 + j) * 64 + lane) * 2 + my_pt] = hbits;
                     ebuf[(L::EBUF_ONE_B / 8) + ((my_t0 + j) * 64 + lane) * 2 + my_pt] = lbits;
+                } else {
+                    bf16x4_t eb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) eb[r] = (__bf16)e[j][r];
+                    uint2 ebits = __builtin_bit_cast(uint2, eb);
+                    ebits.x ^= flip; ebits.y ^= flip;
+                    ebuf[((my_t0 + j) * 64 + lane) * 2 + my_pt] = ebits;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -438,18 +460,19 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
                 const bf16x8_t ab2 = __builtin_bit_cast(bf16x8_t, av);
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
-                    acc[db][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab2, Eb[t], acc[db][t], 0, 0, 0);
+                    acc[db][t] = mfma16<SPLIT>(ab2, Eb[t], acc[db][t]);
                 if constexpr (SPLIT) {
                     const s16x8_t lv = __builtin_shufflevector(gl[db][0], gl[db][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     const bf16x8_t al2 = __builtin_bit_cast(bf16x8_t, lv);
 #pragma unroll
                     for (int t = 0; t < RT; ++t) {
-                        acc[db][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab2, El[t], acc[db][t], 0, 0, 0);
-                        acc[db][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al2, Eb[t], acc[db][t], 0, 0, 0);
+                        acc[db][t] = mfma16<SPLIT>(ab2, El[t], acc[db][t]);
+                        acc[db][t] = mfma16<SPLIT>(al2, Eb[t], acc[db][t]);
                     }
                 }
-#pragma unroll
-                for (int t = 0; t < RT; ++t) asm volatile("" ::"v"(acc[db][t]));
+                // the MFMAs of block db are issued (so their operand reads have completed) before its refill below;
+                // a scheduling fence, not an operand constraint: the accumulators may live in either register half
+                __builtin_amdgcn_sched_barrier(0);
                 // features [32 s, 32 s + 32) of the step are dead after block 2 s + 1 -> refill both point tiles
                 if (db & 1) dma_pair(Xn, db >> 1);
             }

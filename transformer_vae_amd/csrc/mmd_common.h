@@ -10,6 +10,7 @@ constexpr int TILE_P = 16;
 struct MmdArgs {
     const float* cols[2];    // padded fp32 copies: [0] = z_all, [1] = y_all, row stride DPAD
     const float* cols_lo[2]; // split-bf16 kernels: the lo copies (cols[] are then the hi copies); else unused
+    const unsigned* split_amax;   // split kernels: bits of max |value| over both sets (see split_scales)
     const float* cnorm[2];   // squared norms (0 for padding rows)
     int n_rows, n_cols, row_offset;
     int row_blocks, col_splits, tiles_per_set, n_rows_pad;
@@ -57,6 +58,19 @@ __device__ __forceinline__ EQ em1_split_tiny(float t) {
 }
 constexpr float EM1_TINY = 1.f / 256.f;
 constexpr float EM1_POLY_MAX = 0.125f;     // beyond: library exp; |E| >= 0.1175 there, so Q = E + t keeps 20 bits
+
+// Split-fp16 mode: fp32 values are held as fp16 pairs hi + lo of s * v, s = 2^(11 - floor(log2 amax)) so that the
+// largest magnitude of the call lands in [2^11, 2^12) (fp16 keeps 11 bits there and its smallest steps, 2^-24, are
+// 2^-35 of it); E in (-1, 0] is scaled by 2^12.  All scales are powers of two: exact to apply and to undo.
+constexpr float SPLIT_E_SCALE = 4096.f;
+struct SplitScales { float s, inv_s2, grad_unscale; };
+__device__ __forceinline__ SplitScales split_scales(unsigned amax_bits) {
+    const float amax = __uint_as_float(amax_bits);
+    int e = 0;
+    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &e);      // amax = m 2^e, m in [0.5, 1)
+    const float s = ldexpf(1.f, 12 - e);                            // s amax in [2^11, 2^12)
+    return SplitScales{s, ldexpf(1.f, 2 * (e - 12)), ldexpf(1.f, e - 12) / SPLIT_E_SCALE};
+}
 
 // LDS-DMA: every lane moves 16 B (dma16) or 4 B (dma4) global -> LDS at m0_base + lane*size.
 // Issued from inline asm so that hipcc neither counts it in its vmcnt bookkeeping nor drains it

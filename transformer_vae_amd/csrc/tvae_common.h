@@ -44,6 +44,8 @@ __device__ __forceinline__ float to_f32(bf16 v) { return __bfloat162float(v); }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return __float2bfloat16(v); }
+__device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
+template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t u16) { return __uint_as_float(u16 << 16); }
 

@@ -184,6 +184,14 @@ class _LatentDecode(torch.autograd.Function):
         return dz_out, cast(dWd, w_dtype), cast(dbd, w_dtype), cast(dgamma, g_dtype), cast(dbeta, g_dtype), None
 
 
+def _mmd_code(dt: torch.dtype, strict_fp32: bool) -> int:
+    """dtype code of a tvae_mmd_* call: fp32 inputs run the split-fp16 products (three matrix-core products per fp32
+    product, same 1e-5 accuracy class) unless ``strict_fp32`` asks for the fp32-input matrix instruction."""
+    if dt == torch.float32 and strict_fp32:
+        return _lib.TVAE_F32_STRICT
+    return _DTYPES[dt]
+
+
 class _MMDRegulariser(torch.autograd.Function):
     """reg = MMD(prior, latent) * scale, forward and gradient in one device pass
     (reference: autoencoders.py:117-136; closed-form gradient SURVEY.md 8a).
@@ -194,9 +202,10 @@ class _MMDRegulariser(torch.autograd.Function):
 
     @staticmethod
     @_on_tensor_device
-    def forward(ctx, z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float):
+    def forward(ctx, z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float, strict_fp32: bool = False):
         _require_device(z_all, "MMD regulariser")
         dt = torch.bfloat16 if (z_all.dtype == torch.bfloat16 and y_all.dtype == torch.bfloat16) else torch.float32
+        code = _mmd_code(dt, strict_fp32)
         za = z_all.detach().to(dt).contiguous()
         ya = y_all.detach().to(dt).contiguous()
         n_total, D = za.shape
@@ -206,14 +215,14 @@ class _MMDRegulariser(torch.autograd.Function):
         want_grad = bool(ctx.needs_input_grad[0])
         dev = za.device
         lib = _lib.lib()
-        ws_bytes = lib.tvae_mmd_workspace_bytes_for(n_total, n_rows, D, int(want_grad), _DTYPES[dt])
+        ws_bytes = lib.tvae_mmd_workspace_bytes_for(n_total, n_rows, D, int(want_grad), code)
         if ws_bytes < 0:
             raise RuntimeError(f"MMD regulariser: unsupported problem size (n_total={n_total}, n_rows={n_rows}, D={D})")
         ws = _workspace(ws_bytes, dev)
         sums = torch.empty(3, dtype=torch.float64, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         dz = torch.empty((n_rows, D), dtype=dt, device=dev) if want_grad else None
-        _lib.check(lib.tvae_mmd_fwd_bwd(_ptr(za), _ptr(ya), n_total, int(row_offset), n_rows, D, _DTYPES[dt],
+        _lib.check(lib.tvae_mmd_fwd_bwd(_ptr(za), _ptr(ya), n_total, int(row_offset), n_rows, D, code,
                                         _ptr(sums), _ptr(loss), float(loss_scale), _ptr(dz), float(grad_scale),
                                         _ptr(ws), ws.numel(), _stream(za)), "tvae_mmd_fwd_bwd")
         if want_grad:
@@ -227,7 +236,7 @@ class _MMDRegulariser(torch.autograd.Function):
     def backward(ctx, g_loss, _g_sums):
         (dz,) = ctx.saved_tensors
         g = (dz.float() * g_loss.float()).to(ctx.z_dtype)
-        return g, None, None, None, None, None
+        return g, None, None, None, None, None, None
 
 
 class _BottleneckStep(torch.autograd.Function):
@@ -240,7 +249,7 @@ class _BottleneckStep(torch.autograd.Function):
 
     @staticmethod
     @_on_tensor_device
-    def forward(ctx, h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float):
+    def forward(ctx, h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float, strict_fp32: bool = False):
         ctx.set_materialize_grads(False)
         dt = h.dtype
         hc = h if h.stride(2) == 1 else h.contiguous()
@@ -264,14 +273,15 @@ class _BottleneckStep(torch.autograd.Function):
         ya = prior.reshape(N, L).to(mdt).contiguous()
         want_grad = any(ctx.needs_input_grad[:3])
         loss_scale, grad_scale = mmd_scales(B, n_eff, N, L)
-        ws_bytes = lib.tvae_mmd_workspace_bytes_for(N, N, L, int(want_grad), _DTYPES[mdt])
+        mcode = _mmd_code(mdt, strict_fp32)
+        ws_bytes = lib.tvae_mmd_workspace_bytes_for(N, N, L, int(want_grad), mcode)
         if ws_bytes < 0:
             raise RuntimeError(f"MMD regulariser: unsupported problem size (n_total={N}, D={L})")
         ws = _workspace(ws_bytes, dev)
         sums = torch.empty(3, dtype=torch.float64, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         dz_mmd = torch.empty((N, L), dtype=mdt, device=dev) if want_grad else None
-        _lib.check(lib.tvae_mmd_fwd_bwd(_ptr(za), _ptr(ya), N, 0, N, L, _DTYPES[mdt], _ptr(sums), _ptr(loss),
+        _lib.check(lib.tvae_mmd_fwd_bwd(_ptr(za), _ptr(ya), N, 0, N, L, mcode, _ptr(sums), _ptr(loss),
                                         float(loss_scale), _ptr(dz_mmd), float(grad_scale), _ptr(ws), ws.numel(),
                                         stream), "tvae_mmd_fwd_bwd")
         # --- decode (autoencoders.py:38-39, 66-67)
@@ -350,7 +360,7 @@ class _BottleneckStep(torch.autograd.Function):
                 _lib.check(lib.tvae_encode_bwd(_ptr(dz), _ptr(z), _ptr(hc), hc.stride(0), hc.stride(1), _ptr(Wc),
                                                _ptr(dh), _ptr(dWe), _ptr(dbe), B, S, n_eff, d, L, code,
                                                _ptr(ws), ws.numel(), stream), "tvae_encode_bwd")
-        return dh, dWe, dbe, dWd, dbd, dgamma, dbeta, None, None, None
+        return dh, dWe, dbe, dWd, dbd, dgamma, dbeta, None, None, None, None
 
 
 class _Upsample(torch.autograd.Function):
@@ -408,22 +418,23 @@ def mmd_scales(batch_size: int, n_latents: int, n_total: int, dim: int):
     return loss_scale, grad_scale
 
 
-def mmd_reg_loss(latent2d, prior, batch_size: int, n_latents: int):
+def mmd_reg_loss(latent2d, prior, batch_size: int, n_latents: int, strict_fp32: bool = False):
     """Single-device regulariser: MMD(prior, latent) / batch_size * n_latents, fp32 scalar."""
     n_total, dim = latent2d.shape
     ls, gs = mmd_scales(batch_size, n_latents, n_total, dim)
-    loss, _ = _MMDRegulariser.apply(latent2d, latent2d, prior, 0, ls, gs)
+    loss, _ = _MMDRegulariser.apply(latent2d, latent2d, prior, 0, ls, gs, bool(strict_fp32))
     return loss
 
 
-def mmd_row_block(z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float):
+def mmd_row_block(z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float, strict_fp32: bool = False):
     """Row-sharded building block: returns (local loss share, float64[3] partial sums)."""
-    return _MMDRegulariser.apply(z_rows, z_all, y_all, int(row_offset), float(loss_scale), float(grad_scale))
+    return _MMDRegulariser.apply(z_rows, z_all, y_all, int(row_offset), float(loss_scale), float(grad_scale),
+                                 bool(strict_fp32))
 
 
-def bottleneck_step(h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float):
+def bottleneck_step(h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float, strict_fp32: bool = False):
     """(latent, reconstructed_encoding, reg_loss) of the stock bottleneck as one autograd node."""
-    return _BottleneckStep.apply(h, We, be, Wd, bd, gamma, beta, prior, int(n_tokens), float(eps))
+    return _BottleneckStep.apply(h, We, be, Wd, bd, gamma, beta, prior, int(n_tokens), float(eps), bool(strict_fp32))
 
 
 def upsample(x, stride: int, target_len: int, separate_cls: bool = True, truncate_seq: bool = False):
