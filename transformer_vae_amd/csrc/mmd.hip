@@ -788,7 +788,8 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
 // ---- host side ------------------------------------------------------------------------
 struct Plan {
     int bf16_tiles;   // 1: bf16 copies + mmd_bf16_kernel<KB = DPAD / 128> (bf16 inputs, or split fp32 inputs, D > 192)
-    int split;        // 1 (with bf16_tiles): fp32 inputs as hi + lo bf16 copies, three products per fp32 product
+    int split;        // 1 (with bf16_tiles): fp32 inputs as hi + lo fp16 copies, three products per fp32 product
+    int pipe;         // 1 (with bf16_tiles): the gradient launch runs mmd_pipe_kernel (64 rows, software-pipelined)
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
@@ -804,10 +805,10 @@ struct Shape { int dpad, waves, nb; };
 const Shape kShapes[] = {{16, 1, 1}, {32, 1, 2}, {48, 1, 3}, {64, 1, 4}, {80, 1, 5}, {96, 1, 6}, {112, 1, 7},
                          {128, 1, 8}, {160, 1, 10}, {192, 1, 12}, {256, 4, 4}, {384, 4, 6},
                          {512, 4, 8}, {768, 4, 12}, {1024, 8, 8}};
-#ifndef TVAE_SPLIT_RT4_MAX_KB
-#define TVAE_SPLIT_RT4_MAX_KB 6
+#ifndef TVAE_PIPE_MAX_KB
+#define TVAE_PIPE_MAX_KB 6
 #endif
-constexpr int kSplitRt4MaxKb = TVAE_SPLIT_RT4_MAX_KB;    // split gradient launch: 64-row blocks up to this many feature blocks
+constexpr int kPipeMaxKb = TVAE_PIPE_MAX_KB;    // pipelined gradient kernel up to this many feature blocks per wave (0: off)
 const Shape* pick_shape(int64_t D) {
     for (const Shape& sh : kShapes)
         if (sh.dpad >= D) return &sh;
@@ -849,16 +850,17 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     const int rows_wg = p->narrow64 ? 64 : ROWS_PER_WG;
     p->n_pad = (int)align_up(n_total, rows_wg);      // whole 32- (64-) point blocks (symmetric y-y enumeration)
     p->row_blocks = (int)((n_rows + rows_wg - 1) / rows_wg);
-    // bf16 inputs: 64-row blocks (RT = 4) lose the second resident workgroup and measured slower (see Bf16Lds).
-    // Split fp32 inputs: one workgroup per CU either way (its hi + lo point tile is 96 KiB at D = 768) and three
-    // times the matrix work per byte: 64 rows halve the L2 -> LDS stream.
-    p->RT = (p->split && want_grad && p->NB <= kSplitRt4MaxKb) ? 4 : 2;
+    // Gradient launch of the 16-bit matrix-core modes: mmd_pipe_kernel, 64 rows per workgroup (half the L2 -> LDS
+    // stream of 32-row blocks; one workgroup per CU, its vector work software-pipelined between the matrix
+    // instructions), for up to 6 feature blocks per wave (D <= 768: registers).  Wider: mmd_bf16_kernel, 32 rows.
+    p->pipe = (bf16_tiles && want_grad && p->NB <= kPipeMaxKb) ? 1 : 0;
+    p->RT = p->pipe ? 4 : 2;
     p->row_blocks_g = p->narrow64 ? p->row_blocks : (int)((n_rows + 16 * p->RT - 1) / (16 * p->RT));
     p->n_rows_pad = p->narrow64 ? p->row_blocks * 64 : p->row_blocks_g * 16 * p->RT;
     p->tiles_per_set = p->n_pad / TILE_P;
     // Column splits: enough workgroups to fill the chip, and a count that fills the LAST round of
     // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
-    const int wg_per_cu = bf16_tiles ? ((!p->split && p->RT == 2 && p->NB <= 6) ? 2 : 1)
+    const int wg_per_cu = bf16_tiles ? ((!p->split && !p->pipe && p->NB <= 6) ? 2 : 1)
                                      : (p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1));
     const int slots = 256 * wg_per_cu;
     // at least 32 of the 2 * tiles_per_set column tiles per split (4 when the whole problem is tiny)
@@ -884,7 +886,11 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     if (bf16_tiles) {
         const int64_t col_bytes = 2ll * p->n_pad * p->DPAD * (p->split ? 4 : 2);
         if (col_bytes > (64ll << 20)) {
-            int64_t want = (col_bytes + (24ll << 20) - 1) / (24ll << 20);
+            // chunk size: ~24 MB for the one-product kernels (a step lasts ~1 us); the split kernels do three times the
+            // matrix work per byte (~5 us per step) and are at their best with ~96 MB (cfg4 size: 1 split 1 435 ms,
+            // 4 -> 1 353, 8 -> 1 252, 16 -> 1 217, 32 -> 1 225, 63 -> 1 232)
+            const int64_t chunk = p->split ? (96ll << 20) : (24ll << 20);
+            int64_t want = (col_bytes + chunk - 1) / chunk;
             const int64_t hard_max = p->tiles_per_set / 16 < 64 ? p->tiles_per_set / 16 : 64;   // >= 16 tiles of a set per split
             if (want > hard_max) want = hard_max;
             const int64_t slab = (int64_t)p->n_rows_pad * p->DPAD * 4;
@@ -998,7 +1004,8 @@ int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
 
 template <bool GRAD>
 int launch_tiles(const Plan& p, const MmdArgs& a, int nblocks, hipStream_t s) {
-    if (p.bf16_tiles) return launch_mmd_bf16(GRAD, p.split != 0, p.NB, GRAD ? p.RT : 2, a, nblocks, s);
+    if (p.bf16_tiles && GRAD && p.pipe) return launch_mmd_pipe(p.split != 0, p.NB, a, nblocks, s);
+    if (p.bf16_tiles) return launch_mmd_bf16(GRAD, p.split != 0, p.NB, 2, a, nblocks, s);
     if (p.narrow64) return launch_mmd_narrow(GRAD, p.NB, a, nblocks, s);
     return launch_tile_shape<GRAD>(p.DPAD, a, nblocks, s);
 }

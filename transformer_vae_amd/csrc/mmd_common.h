@@ -142,6 +142,8 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 // split: fp32 values as hi + lo bf16 pairs, three products per fp32 product; rt = 16-row tiles per workgroup (2, or 4
 // for the split gradient launch with kb <= 6)
 int launch_mmd_bf16(bool grad, bool split, int kb, int rt, const MmdArgs& a, int nblocks, hipStream_t s);
+// software-pipelined gradient kernel of the 16-bit matrix-core modes, 64 rows per workgroup (mmd_pipe.hip); kb = 2..6
+int launch_mmd_pipe(bool split, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 // fp32 kernel for narrow latents, 64 rows per single-wave workgroup (mmd_narrow.hip); nb = padded dimension / 16 (1..5)
 int launch_mmd_narrow(bool grad, int nb, const MmdArgs& a, int nblocks, hipStream_t s);
 
