@@ -790,6 +790,7 @@ struct Plan {
     int bf16_tiles;   // 1: bf16 copies + mmd_bf16_kernel<KB = DPAD / 128> (bf16 inputs, or split fp32 inputs, D > 192)
     int split;        // 1 (with bf16_tiles): fp32 inputs as hi + lo fp16 copies, three products per fp32 product
     int pipe;         // 1 (with bf16_tiles): the gradient launch runs mmd_pipe_kernel (64 rows, software-pipelined)
+    int pipe_sum;     // 1 (with bf16_tiles): the sum-only launches run mmd_pipe_sum_kernel (64-row blocks too)
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
@@ -808,6 +809,10 @@ const Shape kShapes[] = {{16, 1, 1}, {32, 1, 2}, {48, 1, 3}, {64, 1, 4}, {80, 1,
 #ifndef TVAE_PIPE_MAX_KB
 #define TVAE_PIPE_MAX_KB 6
 #endif
+#ifndef TVAE_PIPE_SUM_BF16
+#define TVAE_PIPE_SUM_BF16 1
+#endif
+constexpr bool kPipeSumBf16 = TVAE_PIPE_SUM_BF16 != 0;   // bf16 mode: sum-only launches on the pipelined kernel too
 constexpr int kPipeMaxKb = TVAE_PIPE_MAX_KB;    // pipelined gradient kernel up to this many feature blocks per wave (0: off)
 const Shape* pick_shape(int64_t D) {
     for (const Shape& sh : kShapes)
@@ -847,20 +852,24 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
         const int64_t cs64 = tps64 >= 32 ? (tps64 / 16 < 64 ? tps64 / 16 : 64) : 1;
         p->narrow64 = ((n_rows + 63) / 64) * cs64 >= 2048 ? 1 : 0;
     }
-    const int rows_wg = p->narrow64 ? 64 : ROWS_PER_WG;
+    // Launches of the 16-bit matrix-core modes: mmd_pipe_kernel / mmd_pipe_sum_kernel, 64 rows per workgroup (half the
+    // L2 -> LDS stream of 32-row blocks; one workgroup per CU, its vector work software-pipelined between the matrix
+    // instructions), for up to 6 feature blocks per wave (D <= 768: registers).  Wider: mmd_bf16_kernel, 32 rows.
+    // The pipelined kernels address points with 32-bit element offsets (and the lo copy of split mode through a
+    // 32-bit byte offset from the hi copy).
+    const bool pipe_ok = bf16_tiles && p->NB <= kPipeMaxKb && align_up(n_total, 64) * p->DPAD < (1ll << 31) - (1ll << 20);
+    p->pipe = (pipe_ok && want_grad) ? 1 : 0;
+    p->pipe_sum = (pipe_ok && (p->split || kPipeSumBf16)) ? 1 : 0;
+    const int rows_wg = (p->narrow64 || p->pipe_sum) ? 64 : ROWS_PER_WG;
     p->n_pad = (int)align_up(n_total, rows_wg);      // whole 32- (64-) point blocks (symmetric y-y enumeration)
     p->row_blocks = (int)((n_rows + rows_wg - 1) / rows_wg);
-    // Gradient launch of the 16-bit matrix-core modes: mmd_pipe_kernel, 64 rows per workgroup (half the L2 -> LDS
-    // stream of 32-row blocks; one workgroup per CU, its vector work software-pipelined between the matrix
-    // instructions), for up to 6 feature blocks per wave (D <= 768: registers).  Wider: mmd_bf16_kernel, 32 rows.
-    p->pipe = (bf16_tiles && want_grad && p->NB <= kPipeMaxKb) ? 1 : 0;
-    p->RT = p->pipe ? 4 : 2;
+    p->RT = (p->pipe || p->pipe_sum) ? 4 : 2;
     p->row_blocks_g = p->narrow64 ? p->row_blocks : (int)((n_rows + 16 * p->RT - 1) / (16 * p->RT));
     p->n_rows_pad = p->narrow64 ? p->row_blocks * 64 : p->row_blocks_g * 16 * p->RT;
     p->tiles_per_set = p->n_pad / TILE_P;
     // Column splits: enough workgroups to fill the chip, and a count that fills the LAST round of
     // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
-    const int wg_per_cu = bf16_tiles ? ((!p->split && !p->pipe && p->NB <= 6) ? 2 : 1)
+    const int wg_per_cu = bf16_tiles ? ((!p->split && !p->pipe && !p->pipe_sum && p->NB <= 6) ? 2 : 1)
                                      : (p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1));
     const int slots = 256 * wg_per_cu;
     // at least 32 of the 2 * tiles_per_set column tiles per split (4 when the whole problem is tiny)
@@ -1004,7 +1013,8 @@ int launch_tile_shape(int dpad, const MmdArgs& a, int nblocks, hipStream_t s) {
 
 template <bool GRAD>
 int launch_tiles(const Plan& p, const MmdArgs& a, int nblocks, hipStream_t s) {
-    if (p.bf16_tiles && GRAD && p.pipe) return launch_mmd_pipe(p.split != 0, p.NB, a, nblocks, s);
+    if (p.bf16_tiles && GRAD && p.pipe) return launch_mmd_pipe(true, p.split != 0, p.NB, a, nblocks, s);
+    if (p.bf16_tiles && !GRAD && p.pipe_sum) return launch_mmd_pipe(false, p.split != 0, p.NB, a, nblocks, s);
     if (p.bf16_tiles) return launch_mmd_bf16(GRAD, p.split != 0, p.NB, 2, a, nblocks, s);
     if (p.narrow64) return launch_mmd_narrow(GRAD, p.NB, a, nblocks, s);
     return launch_tile_shape<GRAD>(p.DPAD, a, nblocks, s);
@@ -1145,7 +1155,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
 #ifdef TVAE_DEBUG_ENV
     if (getenv("TVAE_DEBUG_SP_MAJOR")) a.sp_major = atoi(getenv("TVAE_DEBUG_SP_MAJOR"));          // experiments only
 #endif
-    const int sym_rows = p.narrow64 ? 64 : ROWS_PER_WG;      // row block of the symmetric y-y enumeration
+    const int sym_rows = (p.narrow64 || p.pipe_sum) ? 64 : ROWS_PER_WG;      // row block of the symmetric y-y enumeration
     a.sym = (row_offset % sym_rows == 0 && (n_rows % sym_rows == 0 || row_offset + n_rows == n_total)) ? 1 : 0;
     a.wg_sums = reinterpret_cast<double*>(ws + p.off_sums);
     a.wg_rowsum = reinterpret_cast<double*>(ws + p.off_rowsum);

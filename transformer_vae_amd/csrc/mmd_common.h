@@ -143,7 +143,7 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 // for the split gradient launch with kb <= 6)
 int launch_mmd_bf16(bool grad, bool split, int kb, int rt, const MmdArgs& a, int nblocks, hipStream_t s);
 // software-pipelined gradient kernel of the 16-bit matrix-core modes, 64 rows per workgroup (mmd_pipe.hip); kb = 2..6
-int launch_mmd_pipe(bool split, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
+int launch_mmd_pipe(bool grad, bool split, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 // fp32 kernel for narrow latents, 64 rows per single-wave workgroup (mmd_narrow.hip); nb = padded dimension / 16 (1..5)
 int launch_mmd_narrow(bool grad, int nb, const MmdArgs& a, int nblocks, hipStream_t s);
 

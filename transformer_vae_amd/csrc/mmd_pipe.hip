@@ -17,9 +17,9 @@
 //
 // SPLIT = false: bf16 inputs, 32-point steps (layouts of mmd_bf16_kernel, RT = 4).
 // SPLIT = true : fp32 inputs as scaled fp16 pairs hi + lo (mmd_common.h, split_scales), 16-point steps so that two
-//   hi + lo tiles fit the LDS.  The gradient's K = 32 then holds 16 points TWICE:
-//       acc += [X_hi | X_lo]^T [E_hi ; E_hi]  +  [X_hi | X_hi]^T [E_lo ; E_lo2]          (E = hi + lo + lo2)
-//   i.e. X_hi E_hi + X_lo E_hi + X_hi (E_lo + E_lo2) in two matrix instructions per 16 x 16 output block.
+//   hi + lo tiles fit the LDS.  The Gram stays on 16x16x32 tiles (K = 32 features); the gradient, whose K is the
+//   step's 16 points, runs on v_mfma_f32_32x32x16_f16: 32 features x 32 rows per instruction, three instructions
+//   (X_hi E_hi + X_lo E_hi + X_hi E_lo) per output block, a quarter of the instruction count of 16x16 tiles.
 #include <type_traits>
 
 #include "mmd_common.h"
@@ -50,25 +50,36 @@ struct PipeLds {
     static constexpr int NT = PT * RT;                        // S' tiles per step
     static constexpr int TPW = NT / 4;                        // ... finished per wave
     static constexpr int SW = 32 * KB;                        // features per wave
-    static constexpr int IMG_B = P * SW * 2;                  // one image (hi or lo) of a wave's slice of a step
-    static constexpr int SLICE_B = (SPLIT ? 2 : 1) * IMG_B;   // SPLIT: the hi image, then the lo image
+    // a wave's slice of a step: KB blocks of 32 features, each 2 KiB = two 1 KiB pieces of 16 points x 32 features
+    // (bf16: the step's two point tiles; split: the hi image and the lo image of its one point tile)
+    static constexpr int SLICE_B = KB * 2048;
     static constexpr int XBUF_B = 4 * SLICE_B;                // one point-tile buffer (four wave slices)
     static constexpr int NORM_OFF = 2 * XBUF_B;               // [2 buf][4 waves][64] float point norms (P used; the DMA moves 64)
     static constexpr int XCH_OFF = NORM_OFF + 2 * 4 * 64 * 4;
     static constexpr int XCH_ONE_B = NT * 3 * 64 * 16;        // [tile][3 remote sources][64 lanes] float4
     static constexpr int EBUF_OFF = XCH_OFF + 2 * XCH_ONE_B;
-    static constexpr int EPIECE_B = SPLIT ? RT * 16 * 32 : RT * 64 * 16;   // SPLIT: [t][row][16 points]; else [t][lane][2 pt][4]
-    static constexpr int EBUF_ONE_B = (SPLIT ? 3 : 1) * EPIECE_B;
+    static constexpr int EPIECE_B = SPLIT ? 64 * 32 : RT * 64 * 16;        // SPLIT: [row][16 points]; else [t][lane][2 pt][4]
+    static constexpr int EBUF_ONE_B = (SPLIT ? 2 : 1) * EPIECE_B;          // SPLIT: hi piece, lo piece
     static constexpr int BYTES = EBUF_OFF + 2 * EBUF_ONE_B;
     static_assert(BYTES <= 160 * 1024, "pipelined tile kernel exceeds the 160 KiB LDS");
     static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses an exchange buffer");
 };
 
+#ifndef TVAE_PIPE_TD
+#define TVAE_PIPE_TD 2
+#endif
+#ifndef TVAE_PIPE_GD
+#define TVAE_PIPE_GD 1
+#endif
+
+template <int V> using ic = std::integral_constant<int, V>;
+
 template <int KB, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     using L = PipeLds<KB, SPLIT>;
     constexpr int P = L::P, PT = L::PT, RT = L::RT, TPW = L::TPW, SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;
-    constexpr int DPS = 2;                                    // DMA instructions per 32-feature block (pair of point tiles / hi + lo)
+    constexpr int NE = 4 * TPW;                               // E values per lane and step
+    constexpr int DPS = 2;                                    // DMA instructions per 32-feature block
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,11 +141,17 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     for (int j = 0; j < TPW; ++j) asm volatile("" : "+v"(rn[j]));
     const bool any_invalid = __any(!all_valid);
 
-    f32x4 acc[NI][RT];
+    // gradient accumulators.  bf16: acc[16-feature block][row tile], 16x16 tiles.  split: acc[32-feature block][32-row
+    // block], 32x32 tiles (v_mfma_f32_32x32x16_f16: K = this step's 16 points)
+    using AccT = std::conditional_t<SPLIT, f32x16, f32x4>;
+    constexpr int AN0 = SPLIT ? KB : NI, AN1 = SPLIT ? 2 : RT;
+    AccT acc[AN0][AN1];
 #pragma unroll
-    for (int db = 0; db < NI; ++db)
+    for (int x = 0; x < AN0; ++x)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[db][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int y = 0; y < AN1; ++y)
+#pragma unroll
+            for (int r = 0; r < (SPLIT ? 16 : 4); ++r) acc[x][y][r] = 0.f;
 
     // steps of P points over both column sets: [0, nS) latents, [nS, 2 nS) priors
     const int nS = a.tiles_per_set / PT;
@@ -146,39 +163,46 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     // ---- per-lane constants of the LDS images (one 1 KiB piece = 16 points x 32 features, mmd_bf16.hip) ----
     const int dma_r = lane >> 2, dma_c = (lane & 3) ^ (2 * ((lane >> 4) & 1));
     const unsigned dma_voff = (unsigned)(dma_r * DPAD + 8 * dma_c) * 2u;
-    const unsigned dma_voff_b = dma_voff + 16u * DPAD * 2u - 1024u;      // second point tile of a pair (dma16_pair)
+    // second piece of a block, 1 KiB further in LDS through the instruction offset (dma16_pair), which the hardware
+    // adds to the global address too: the second point tile (bf16), or the lo copy of the same tile (split; the plan
+    // keeps the distance between the copies below 2^32 bytes)
+    const unsigned dma_voff_b = SPLIT ? dma_voff + (unsigned)(reinterpret_cast<const char*>(a.cols_lo[0]) - reinterpret_cast<const char*>(a.cols[0])) - 1024u
+                                      : dma_voff + 16u * DPAD * 2u - 1024u;
     const int gram_off = 16 * (4 * i16 + (g ^ (2 * ((i16 >> 2) & 1))));  // + 1024 * piece
     const int tq = i16 >> 2, tp = i16 & 3;
-    // transposed reads of 16-feature block db: piece (db >> 1), base by the parity of db
-    int tr_off[2][2];                 // bf16: [parity][0]; split: [parity][h = which four of a lane group's eight points]
+    // transposed operand reads (ds_read_b64_tr_b16: the 16 lanes of a group fetch 4 points x 16 features and lane i
+    // receives feature i of the four points).
+    //   bf16, 16-feature block db (16x16x32: k = 8 g + .. over 32 points): piece pair db >> 1, base by the parity of db
+    //   split, 32-feature block (32x32x16: feature = lane % 32, k = 8 (lane / 32) + 4 h + ..): [h]
+    int tr_off[2];
     if constexpr (SPLIT) {
 #pragma unroll
-        for (int par = 0; par < 2; ++par)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                tr_off[par][h] = 16 * (4 * (8 * (g & 1) + 4 * h + tq) + ((2 * par + (tp >> 1)) ^ (2 * h))) + 8 * (tp & 1);
+        for (int h = 0; h < 2; ++h)
+            tr_off[h] = 64 * (8 * (g >> 1) + 4 * h + tq) + 16 * ((2 * (g & 1) + (tp >> 1)) ^ (2 * h)) + 8 * (tp & 1);
     } else {
-        tr_off[0][0] = 16 * (4 * (4 * g + tq) + 2 * (g & 1) + (tp >> 1)) + 8 * (tp & 1);
-        tr_off[1][0] = 16 * (4 * (4 * g + tq) + 2 * ((g & 1) ^ 1) + (tp >> 1)) + 8 * (tp & 1);
-        tr_off[0][1] = tr_off[1][1] = 0;
+        tr_off[0] = 16 * (4 * (4 * g + tq) + 2 * (g & 1) + (tp >> 1)) + 8 * (tp & 1);
+        tr_off[1] = 16 * (4 * (4 * g + tq) + 2 * ((g & 1) ^ 1) + (tp >> 1)) + 8 * (tp & 1);
     }
     auto tr_read = [&](int byte_off) -> s16x4_t {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4_t*)(__attribute__((address_space(3))) char*)(sm + byte_off));
     };
 
-    struct Src { const bf16* hi; const bf16* lo; const float* nrm; int set; int p0; };
-    auto step_src = [&](int v) -> Src {
+    struct Src { const bf16* x; const float* nrm; int set; int p0; };
+    auto step_meta = [&](int v, int& set, int& p0) {
         const int u = v < se ? v : se - 1;                    // past the end: the last step again (results unused)
-        const int set = u >= nS ? 1 : 0;
+        set = u >= nS ? 1 : 0;
 #ifdef TVAE_DEBUG_SAME_TILE
-        const int p0 = 0 * u;
+        p0 = 0 * u;
 #else
-        const int p0 = (u - set * nS) * P;
+        p0 = (u - (set ? nS : 0)) * P;
 #endif
-        const long long off = (long long)p0 * DPAD + wave * SW;
-        return Src{reinterpret_cast<const bf16*>(a.cols[set]) + off,
-                   SPLIT ? reinterpret_cast<const bf16*>(a.cols_lo[set]) + off : nullptr, a.cnorm[set] + p0, set, p0};
+    };
+    auto step_src = [&](int v) -> Src {
+        int set, p0;
+        step_meta(v, set, p0);
+        const unsigned off = (unsigned)p0 * (unsigned)DPAD + (unsigned)(wave * SW);      // the plan keeps n_pad * DPAD < 2^31
+        return Src{reinterpret_cast<const bf16*>(a.cols[set]) + off, a.cnorm[set] + p0, set, p0};
     };
     auto xbuf_byte = [&](int b) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
     auto stage_norms = [&](const Src& X, int nbuf) {
@@ -186,17 +210,14 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(L::NORM_OFF + (nbuf * 4 + wave) * 64 * 4));
         dma4(uniform_ptr(X.nrm), (unsigned)lane * 4u, dst);
     };
-    // features [32 s, 32 s + 32) of the step into buffer b: two DMA instructions
+    // features [32 s, 32 s + 32) of the step into buffer b: two DMA instructions under one M0
     auto dma_block = [&](const Src& X, int b, int s) {
-        const unsigned base = smem_byte + xbuf_byte(b);
-        if constexpr (SPLIT) {
-            dma16(reinterpret_cast<const float*>(X.hi + 32 * s), dma_voff, base + 1024u * s);
-            dma16(reinterpret_cast<const float*>(X.lo + 32 * s), dma_voff, base + (unsigned)L::IMG_B + 1024u * s);
-        } else {
-            dma16_pair(reinterpret_cast<const float*>(X.hi + 32 * s), dma_voff, dma_voff_b, base + 2048u * s);
-        }
+        dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, dma_voff_b, smem_byte + xbuf_byte(b) + 2048u * s);
     };
 
+#ifdef TVAE_PHASE_TIMING
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
+#endif
     f32x4 S[PT][RT];      // partial Gram accumulators of the tile in flight, local (rotated) tile order
     // reduce-scatter of the partials through exchange buffer xbuf: global tile q = RT pt + t goes to wave q / TPW;
     // in the rotated local order this wave's own tiles are S[0][0 .. TPW-1] and stay in registers
@@ -212,106 +233,148 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
                 *reinterpret_cast<f32x4*>(xb + (q * 3 + ((wave - owner - 1) & 3)) * 1024) = S[pt][t];
             }
     };
-    f32x4 sv[TPW];
-    auto xch_reduce = [&](int xbuf) {
+    // finish the S' tiles of this wave, then t = |x - z|^2 / D^2 per element (register r <-> point p0 + 16 my_pt + 4 g + r,
+    // row i16 of row tile my_t0 + j) and whether any lane leaves the polynomial's range
+    float tt[NE];
+    bool t_big = false;
+    auto xch_reduce = [&](int xbuf, int nbuf) {
         const f32x4* xb = reinterpret_cast<const f32x4*>(sm + L::XCH_OFF + xbuf * L::XCH_ONE_B);
         f32x4 part[TPW][3];
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
 #pragma unroll
-            for (int w = 0; w < 3; ++w) part[j][w] = xb[((wave * TPW + j) * 3 + w) * 64 + lane];     // all reads in flight
+            for (int w = 0; w < 3; ++w) {
+#ifdef TVAE_DEBUG_NO_XCH
+                part[j][w] = S[0][j];
+#else
+                part[j][w] = xb[((wave * TPW + j) * 3 + w) * 64 + lane];     // all reads in flight
+#endif
+            }
+        const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + ((nbuf * 4 + wave) * 64 + 16 * my_pt + 4 * g) * 4);
+        float tm = 0.f;
 #pragma unroll
-        for (int j = 0; j < TPW; ++j)          // own partial (rotated order: still in registers) + the three others, fixed order
-            sv[j] = ((S[0][j] + part[j][0]) + part[j][1]) + part[j][2];
+        for (int j = 0; j < TPW; ++j) {        // own partial (rotated order: still in registers) + the three others, fixed order
+            const f32x4 sv = ((S[0][j] + part[j][0]) + part[j][1]) + part[j][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                tt[4 * j + r] = fmaxf((cn[r] + rn[j] - gram_unscale2 * sv[r]) * a.inv_d2, 0.f);
+                tm = fmaxf(tm, tt[4 * j + r]);
+            }
+        }
+        t_big = __any(tm >= EM1_POLY_MAX);
     };
 
     double sum0 = 0.0, sum1 = 0.0, rowsum[TPW];     // per-lane fp64 partials of the Q sums (by column set) and the row sums
 #pragma unroll
     for (int j = 0; j < TPW; ++j) rowsum[j] = 0.0;
 
+    // k-step 0 operands of the NEXT interval's Gram, read at the end of this one (their LDS round trip would otherwise
+    // open every interval): block 0 of the tile in buffer b has landed once all but the DPS (KB - 1) youngest DMA
+    // instructions have
+    h16x8_t nab[PT], nal[SPLIT ? PT : 1];
+    auto gram_prefetch = [&](int b) {
+        const char* xs = sm + xbuf_byte(b);
+        wait_vmcnt_n(DPS * (KB - 1));
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            if constexpr (SPLIT) {
+                nab[pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off);
+                nal[pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 1024);
+            } else {
+                nab[pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 1024 * ((pt + my_pt) & (PT - 1)));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     // First half of an interval: partial Gram of the tile in buffer b over this wave's feature slice, S[pt'][t'], with
-    // the E work of the PREVIOUS tile (step X: from sv, its norms in nbuf, pieces into E buffer ebuf) cut into KB
+    // the E work of the PREVIOUS tile (set x_set, first point x_p0: from tt, pieces into E buffer ebuf) cut into KB
     // slices that follow the matrix instructions of the KB k-steps.  The counted DMA waits in front of the operand
     // reads are inline asm, which hipcc does not schedule across: each k-step is a scheduling region of its own, and
-    // vector work only lands between matrix instructions it shares a region with.  E = expm1(-t): register r <-> point
-    // p0 + 16 my_pt + 4 g + r, column = row i16 of row tile my_t0 + j; straight-line code (polynomial and exp form both
-    // evaluated and selected); the masks of ragged edges exist only in the EDGE instantiation, which a wave-uniform
-    // branch picks per step.  `slack`: DMA instructions issued after this tile's that may still be in flight;
-    // WITH_E = false: the prologue's Gram.
-    auto front = [&](auto edge_tag, auto with_e_tag, int b, int slack, const Src& X, int nbuf, int ebuf) {
-        constexpr bool EDGE = decltype(edge_tag)::value, WITH_E = decltype(with_e_tag)::value;
-        constexpr int NE = 4 * TPW;                           // E values per lane
+    // vector work only lands between matrix instructions it shares a region with.  E = expm1(-t) as straight-line
+    // code: the polynomial alone in the common instantiation; SLOW adds the exp form for t >= 1/8 and the masks of
+    // ragged edges, and a wave-uniform branch picks it per step.  `slack`: DMA instructions issued after this tile's
+    // that may still be in flight; WITH_E = false: the prologue's Gram.
+    auto front = [&](auto slow_tag, auto with_e_tag, int b, int slack, int x_set, int x_p0, int ebuf) {
+        constexpr bool SLOW = decltype(slow_tag)::value, WITH_E = decltype(with_e_tag)::value;
+        constexpr bool PRE = WITH_E;                          // the loop's intervals: k-step 0 was read ahead (gram_prefetch)
         const char* xs = sm + xbuf_byte(b);
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-            for (int t = 0; t < RT; ++t) S[pt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int GD = KB < 2 ? KB : 2;                   // operand reads run GD k-steps ahead of their MFMAs
+        constexpr int GD = KB < TVAE_PIPE_GD ? KB : TVAE_PIPE_GD;      // operand reads run GD k-steps ahead of their MFMAs
         h16x8_t ab[KB][PT], al[SPLIT ? KB : 1][PT];
         auto rd = [&](int sr) {
+            if (PRE && sr == 0) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) { ab[0][pt] = nab[pt]; if constexpr (SPLIT) al[0][pt] = nal[pt]; }
+                return;
+            }
             wait_vmcnt_n(DPS * (KB - 1 - sr) + slack);
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                const int piece = PT * sr + (PT == 1 ? 0 : ((pt + my_pt) & (PT - 1)));      // local -> global point tile
-                ab[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 1024 * piece);
-                if constexpr (SPLIT) al[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + L::IMG_B + gram_off + 1024 * piece);
+                if constexpr (SPLIT) {
+                    ab[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 2048 * sr);
+                    al[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 2048 * sr + 1024);
+                } else {
+                    const int piece = PT * sr + ((pt + my_pt) & (PT - 1));                   // local -> global point tile
+                    ab[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 1024 * piece);
+                }
             }
+            // keep the reads HERE, ahead of the matrix instructions of the k-steps before sr: left alone, hipcc sinks
+            // them to their first use and every k-step then waits out an LDS round trip (measured: 1 950 cycles for the
+            // 1 152 cycles of matrix work of a split Gram)
+            __builtin_amdgcn_sched_barrier(0);
         };
-        f32x4 cn, e[TPW], q[TPW];
-        if constexpr (WITH_E)
-            cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + ((nbuf * 4 + wave) * 64 + 16 * my_pt + 4 * g) * 4);
+        f32x4 e[TPW], q[TPW];
         auto e_slice = [&](int s) {
-            // elements el = 4 j + r spread over slices 0 .. KB-2; sums, conversion and publication in slice KB-1
+            // elements el = 4 j + r spread over slices 0 .. FIN; sums, conversion and publication at the end of slice FIN,
+            // with the matrix instructions of the last k-step still to come behind them
+            constexpr int FIN = KB > 1 ? KB - 2 : 0;
 #pragma unroll
             for (int el = 0; el < NE; ++el) {
-                if ((KB > 1 ? el * (KB - 1) / NE : 0) != s) continue;
+                if (el * (FIN + 1) / NE != s) continue;
                 const int j = el >> 2, r = el & 3;
-                const float tt = fmaxf((cn[r] + rn[j] - gram_unscale2 * sv[j][r]) * a.inv_d2, 0.f);
-                const EQ pl = em1_split(tt);                                  // t < 1/8
-                const float ex = __expf(-tt) - 1.f;                           // beyond: |E| >= 0.1175, 1e-6 relative
-                const bool big = tt >= EM1_POLY_MAX;
-                float ev = big ? ex : pl.e, qv = big ? ex + tt : pl.q;
-                if constexpr (EDGE) {
-                    const bool ok = my_valid[j] && (X.p0 + 16 * my_pt + 4 * g + r < a.n_cols);
-                    ev = ok ? ev : 0.f;
-                    qv = ok ? qv : 0.f;
+                const EQ pl = em1_split(tt[el]);                                  // t < 1/8
+                float ev = pl.e, qv = pl.q;
+                if constexpr (SLOW) {
+                    const float ex = __expf(-tt[el]) - 1.f;                       // beyond: |E| >= 0.1175, 1e-6 relative
+                    const bool big = tt[el] >= EM1_POLY_MAX;
+                    const bool ok = my_valid[j] && (x_p0 + 16 * my_pt + 4 * g + r < a.n_cols);
+                    ev = ok ? (big ? ex : ev) : 0.f;
+                    qv = ok ? (big ? ex + tt[el] : qv) : 0.f;
                 }
                 e[j][r] = ev;
                 q[j][r] = qv;
             }
-            if (s != KB - 1) return;
+            if (s != FIN) return;
             // sums carry Q (linear part: closed form in the finalize kernel); row sums carry E
             float qs_all = 0.f;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
                 qs_all += (q[j][0] + q[j][1]) + (q[j][2] + q[j][3]);
                 const float es = (e[j][0] + e[j][1]) + (e[j][2] + e[j][3]);
-                rowsum[j] += (double)(X.set ? -es : es);
+                rowsum[j] += (double)(x_set ? -es : es);
             }
-            sum0 += (double)(X.set ? 0.f : qs_all);
-            sum1 += (double)(X.set ? qs_all : 0.f);
+            sum0 += (double)(x_set ? 0.f : qs_all);
+            sum1 += (double)(x_set ? qs_all : 0.f);
             // prior columns enter the gradient with s_p = -1: flip the sign bits of the packed values
-            const unsigned flip = X.set ? 0x80008000u : 0u;
+            const unsigned flip = x_set ? 0x80008000u : 0u;
             char* eb = sm + L::EBUF_OFF + ebuf * L::EBUF_ONE_B;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
                 if constexpr (SPLIT) {
-                    f16x4_t p0v, p1v, p2v;
+                    f16x4_t p0v, p1v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float es = e[j][r] * SPLIT_E_SCALE;
                         p0v[r] = (_Float16)es;
-                        const float r1 = es - (float)p0v[r];
-                        p1v[r] = (_Float16)r1;
-                        p2v[r] = (_Float16)(r1 - (float)p1v[r]);
+                        p1v[r] = (_Float16)(es - (float)p0v[r]);
                     }
-                    uint2 b0 = __builtin_bit_cast(uint2, p0v), b1 = __builtin_bit_cast(uint2, p1v), b2 = __builtin_bit_cast(uint2, p2v);
-                    b0.x ^= flip; b0.y ^= flip; b1.x ^= flip; b1.y ^= flip; b2.x ^= flip; b2.y ^= flip;
-                    // [piece][row tile][row][16 points]: this lane holds points 4 g .. 4 g + 3 of row i16
-                    const int at = ((my_t0 + j) * 16 + i16) * 32 + 8 * g;
+                    uint2 b0 = __builtin_bit_cast(uint2, p0v), b1 = __builtin_bit_cast(uint2, p1v);
+                    b0.x ^= flip; b0.y ^= flip; b1.x ^= flip; b1.y ^= flip;
+                    // [piece][row][16 points], the two 16-byte halves of a row swapped on rows 8 .. 15 of a tile (bank
+                    // spread of the consumer's reads): this lane holds points 4 g .. 4 g + 3 of row 16 (my_t0 + j) + i16
+                    const int at = ((my_t0 + j) * 16 + i16) * 32 + 16 * ((g >> 1) ^ ((i16 >> 3) & 1)) + 8 * (g & 1);
                     *reinterpret_cast<uint2*>(eb + at) = b0;
                     *reinterpret_cast<uint2*>(eb + L::EPIECE_B + at) = b1;
-                    *reinterpret_cast<uint2*>(eb + 2 * L::EPIECE_B + at) = b2;
                 } else {
                     b16x4_t ev;
 #pragma unroll
@@ -322,15 +385,20 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
                 }
             }
         };
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < GD; ++s) rd(s);
+#ifdef TVAE_PHASE_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PHASE_MARK(5);
+#endif
 #pragma unroll
         for (int s = 0; s < KB; ++s) {
             if (s + GD < KB) rd(s + GD);
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(ab[s][pt], zreg[t][s], S[pt][t]);
+                for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(ab[s][pt], zreg[t][s], s == 0 ? zero : S[pt][t]);
             if constexpr (SPLIT) {
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
@@ -341,60 +409,121 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(al[s][pt], zreg[t][s], S[pt][t]);
             }
+#ifndef TVAE_DEBUG_NO_E
             if constexpr (WITH_E) e_slice(s);
+#endif
         }
     };
 
-    // gradient of the tile in buffer b with the E pieces of ebuf: acc^T[d][i] += X^T[d][p] (s_p E[p][i]); block pair s of
-    // the buffer is dead after its MFMAs -> refilled in place with the same block of step Xn
-    auto grad = [&](int b, int ebuf, const Src& Xn) {
+    // gradient of the tile in buffer b with the E pieces of ebuf: acc^T[d][i] += X^T[d][p] (s_p E[p][i]); a 32-feature
+    // block of the buffer is dead after its MFMAs -> refilled in place with the same block of step Xn.
+    // grad_fetch issues the first operand reads (in program order ahead of the exchange reads, so that the matrix
+    // instructions of block 0 can start while the next tile's partials are still being summed); grad_run does the rest.
+    constexpr int GB = SPLIT ? KB : NI;                       // feature blocks of the gradient (32 / 16 features)
+    constexpr int TD = GB < TVAE_PIPE_TD ? GB : TVAE_PIPE_TD; // transposed operand reads run TD blocks ahead
+    h16x8_t Bh[SPLIT ? 2 : RT], Bl[SPLIT ? 2 : 1];
+    s16x4_t gh[GB][2], gl[SPLIT ? GB : 1][2];
+    auto grad_rd = [&](int xb0, int blk) {
+        if constexpr (SPLIT) {
+            const int at = xb0 + 2048 * blk;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                gh[blk][h] = tr_read(at + tr_off[h]);
+                gl[blk][h] = tr_read(at + 1024 + tr_off[h]);
+            }
+        } else {
+            const int at = xb0 + 2048 * (blk >> 1);
+            gh[blk][0] = tr_read(at + tr_off[blk & 1]);
+            gh[blk][1] = tr_read(at + 1024 + tr_off[blk & 1]);
+        }
+    };
+    auto grad_fetch_x = [&](int b) {          // wave-private tile data: legal ahead of the barrier
+#pragma unroll
+        for (int blk = 0; blk < TD; ++blk) grad_rd((int)xbuf_byte(b), blk);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto grad_fetch_e = [&](int ebuf) {
         const char* eb = sm + L::EBUF_OFF + ebuf * L::EBUF_ONE_B;
-        h16x8_t B1[RT], B2[SPLIT ? RT : 1];
+        if constexpr (SPLIT) {
+            // B[k = point][n = row]: lane holds points 8 (lane / 32) .. + 7 of row 32 rbk + lane % 32
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            if constexpr (SPLIT) {
-                const int at = (t * 16 + i16) * 32 + 16 * (g & 1);
-                B1[t] = *reinterpret_cast<const h16x8_t*>(eb + at);
-                B2[t] = *reinterpret_cast<const h16x8_t*>(eb + (g < 2 ? 1 : 2) * L::EPIECE_B + at);
-            } else {
-                B1[t] = *reinterpret_cast<const h16x8_t*>(eb + (t * 64 + lane) * 16);
+            for (int rbk = 0; rbk < 2; ++rbk) {
+                const int n = lane & 31;
+                const int at = (32 * rbk + n) * 32 + 16 * ((lane >> 5) ^ ((n >> 3) & 1));
+                Bh[rbk] = *reinterpret_cast<const h16x8_t*>(eb + at);
+                Bl[rbk] = *reinterpret_cast<const h16x8_t*>(eb + L::EPIECE_B + at);
             }
+        } else {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) Bh[t] = *reinterpret_cast<const h16x8_t*>(eb + (t * 64 + lane) * 16);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto grad_run = [&](int b, const Src& Xn) {
         const int xb0 = (int)xbuf_byte(b);
-        constexpr int TD = NI < 2 ? NI : 2;                   // transposed operand reads run TD blocks ahead
-        s16x4_t ga[NI][2], gb[SPLIT ? NI : 1][2];
-        auto rd = [&](int db) {
-            const int at = xb0 + 1024 * PT * (db >> 1);
+#pragma unroll
+        for (int blk = 0; blk < GB; ++blk) {
+            if (blk + TD < GB) grad_rd(xb0, blk + TD);
             if constexpr (SPLIT) {
-                // A1 = [X_hi | X_lo]: lane groups 0, 1 read the hi image, 2, 3 the lo image; A2 = [X_hi | X_hi]
-                ga[db][0] = tr_read(at + (g >> 1) * L::IMG_B + tr_off[db & 1][0]);
-                ga[db][1] = tr_read(at + (g >> 1) * L::IMG_B + tr_off[db & 1][1]);
-                gb[db][0] = tr_read(at + tr_off[db & 1][0]);
-                gb[db][1] = tr_read(at + tr_off[db & 1][1]);
+                const f16x8_t Ah = __builtin_bit_cast(f16x8_t, __builtin_shufflevector(gh[blk][0], gh[blk][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                const f16x8_t Al = __builtin_bit_cast(f16x8_t, __builtin_shufflevector(gl[blk][0], gl[blk][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                // X_hi E_hi + X_lo E_hi + X_hi E_lo, the two row blocks alternating
+#pragma unroll
+                for (int rbk = 0; rbk < 2; ++rbk)
+                    acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
+#pragma unroll
+                for (int rbk = 0; rbk < 2; ++rbk)
+                    acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
+#pragma unroll
+                for (int rbk = 0; rbk < 2; ++rbk)
+                    acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bl[rbk]), acc[blk][rbk], 0, 0, 0);
             } else {
-                ga[db][0] = tr_read(at + tr_off[db & 1][0]);
-                ga[db][1] = tr_read(at + 1024 + tr_off[db & 1][0]);
+                const h16x8_t A1 = __builtin_bit_cast(h16x8_t, __builtin_shufflevector(gh[blk][0], gh[blk][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int t = 0; t < RT; ++t) acc[blk][t] = mma<false>(A1, Bh[t], acc[blk][t]);
             }
-        };
-#pragma unroll
-        for (int db = 0; db < TD; ++db) rd(db);
-#pragma unroll
-        for (int db = 0; db < NI; ++db) {
-            if (db + TD < NI) rd(db + TD);
-            const h16x8_t A1 = __builtin_bit_cast(h16x8_t, __builtin_shufflevector(ga[db][0], ga[db][1], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-            for (int t = 0; t < RT; ++t) acc[db][t] = mma<SPLIT>(A1, B1[t], acc[db][t]);
-            if constexpr (SPLIT) {
-                const h16x8_t A2 = __builtin_bit_cast(h16x8_t, __builtin_shufflevector(gb[db][0], gb[db][1], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                for (int t = 0; t < RT; ++t) acc[db][t] = mma<SPLIT>(A2, B2[t], acc[db][t]);
-            }
-            if (db & 1) {
-                // the MFMAs of blocks 2 s, 2 s + 1 are issued (their operand reads have completed) before the refill
+            if (SPLIT || (blk & 1)) {
+                // the MFMAs of the 32-feature block are issued (their operand reads have completed) before the refill
                 __builtin_amdgcn_sched_barrier(0);
-                dma_block(Xn, b, db >> 1);
+                dma_block(Xn, b, SPLIT ? blk : blk >> 1);
             }
         }
+    };
+
+    // one interval; the buffer indices are compile-time constants (the loop below is unrolled by two)
+    auto interval = [&](int k, auto cur_tag) {
+#ifdef TVAE_PIPE_UNROLL2
+        constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
+#else
+        const int cur = k & 1, nxt = cur ^ 1;
+#endif
+        int c_set, c_p0;
+        step_meta(sb + k, c_set, c_p0);
+        const Src Xn2 = step_src(sb + k + 2);
+        // Gram of the next tile  ||  E of this one (from tt, left by the previous interval)
+        PHASE_MARK(5);
+        if (any_invalid || t_big || c_p0 + P > a.n_cols) front(std::true_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);   // wave-uniform
+        else front(std::false_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);
+        PHASE_MARK(0);
+        grad_fetch_x(cur);          // in flight while the last matrix instructions of the Gram drain
+#ifndef TVAE_DEBUG_NO_XCH
+        xch_write(nxt);
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PHASE_MARK(1);
+#ifndef TVAE_DEBUG_NO_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+        PHASE_MARK(2);
+        // gradient of this tile (+ refill with tile k + 2)  ||  reduce of the next tile's partials
+        grad_fetch_e(cur);
+        stage_norms(Xn2, cur);
+        xch_reduce(nxt, nxt);
+        PHASE_MARK(3);
+        grad_run(cur, Xn2);
+        gram_prefetch(cur);         // the next interval's Gram runs on the tile just refilled into this buffer
+        PHASE_MARK(4);
     };
 
     if (nsteps > 0) {
@@ -407,30 +536,29 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
             stage_norms(X1, 1);
 #pragma unroll
             for (int s = 0; s < KB; ++s) dma_block(X1, 1, s);
-            front(std::false_type{}, std::false_type{}, 0, 1 + DPS * KB, X0, 0, 0);
+            front(std::false_type{}, std::false_type{}, 0, 1 + DPS * KB, 0, 0, 0);
             xch_write(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            xch_reduce(0);
+            xch_reduce(0, 0);
+            gram_prefetch(1);
         }
-        for (int k = 0; k < nsteps; ++k) {
-            const int cur = k & 1, nxt = cur ^ 1;
-            const Src Xc = step_src(sb + k), Xn2 = step_src(sb + k + 2);
-            // Gram of the next tile  ||  E of this one (from sv, reduced in the previous interval)
-            if (any_invalid || Xc.p0 + P > a.n_cols) front(std::true_type{}, std::true_type{}, nxt, 0, Xc, cur, cur);   // wave-uniform
-            else front(std::false_type{}, std::true_type{}, nxt, 0, Xc, cur, cur);
-            xch_write(nxt);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            // gradient of this tile (+ refill with tile k + 2)  ||  reduce of the next tile's partials
-            stage_norms(Xn2, cur);
-            xch_reduce(nxt);
-            grad(cur, cur, Xn2);
+#ifdef TVAE_PIPE_UNROLL2
+        for (int k = 0; k < nsteps; k += 2) {
+            interval(k, ic<0>{});
+            if (k + 1 < nsteps) interval(k + 1, ic<1>{});
         }
+#else
+        for (int k = 0; k < nsteps; ++k) interval(k, ic<0>{});
+#endif
     }
     wait_vmcnt<0>();
+#ifdef TVAE_PHASE_TIMING
+    if (blockIdx.x == 0 && lane == 0 && nsteps > 0)
+        printf("wave %d steps %d: front %llu  xch write %llu  barrier %llu  fetch+reduce %llu  grad %llu  top %llu (cycles per step)\n", wave,
+               nsteps, ph[0] / nsteps, ph[1] / nsteps, ph[2] / nsteps, ph[3] / nsteps, ph[4] / nsteps, ph[5] / nsteps);
+#endif
 
     // ---- per-workgroup results: each wave holds the sums of ITS tiles; add the four in a fixed order ----
     __syncthreads();
@@ -456,12 +584,300 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         for (int pt = 0; pt < PT; ++pt) r += red[8 + (RT * pt + t) * 16 + i];
         a.wg_rowsum[(long long)sp * a.n_rows_pad + i0 + tid] = r;
     }
+    if constexpr (SPLIT) {
+        // 32x32 tiles: register r of a lane is feature 8 (r / 4) + 4 (lane / 32) + r % 4 of row lane % 32
+#pragma unroll
+        for (int rbk = 0; rbk < 2; ++rbk) {
+            float* grow = a.wg_grad + ((long long)sp * a.n_rows_pad + i0 + 32 * rbk + (lane & 31)) * DPAD + wave * SW + 4 * (lane >> 5);
+#pragma unroll
+            for (int s = 0; s < KB; ++s)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *reinterpret_cast<f32x4*>(grow + 32 * s + 8 * q4) =
+                        f32x4{acc[s][rbk][4 * q4], acc[s][rbk][4 * q4 + 1], acc[s][rbk][4 * q4 + 2], acc[s][rbk][4 * q4 + 3]};
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            float* grow = a.wg_grad + ((long long)sp * a.n_rows_pad + i0 + 16 * t + i16) * DPAD + wave * SW + 4 * g;
+#pragma unroll
+            for (int db = 0; db < NI; ++db) *reinterpret_cast<f32x4*>(grow + 16 * db) = acc[db][t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Sum-only companion: the y-rows launch of a gradient call (y-y, each unordered pair of 64-row blocks once when the
+// row range allows) and both problems of a call without gradient.  Same 64-row blocks, K-sliced Gram and exchange;
+// with no gradient phase an interval is
+//
+//     Gram(k+1)  ||  sum the partials of tile k, expm1, sums          -> write partial S'(k+1) -> ONE barrier
+//
+// and a feature block of the tile under the Gram is refilled right behind its matrix instructions with tile k + 3
+// (two tile buffers: k + 1 under the Gram, k + 2 landed or landing).  Point norms sit in a ring of four.
+// The exp form and the ragged-edge masks are always compiled in (there is vector time to spare without a gradient).
+// ------------------------------------------------------------------------------------------------------------------
+template <int KB, bool SPLIT>
+__global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
+    using L = PipeLds<KB, SPLIT>;
+    constexpr int P = L::P, PT = L::PT, RT = L::RT, TPW = L::TPW, SW = L::SW, DPAD = 4 * SW;
+    constexpr int NE = 4 * TPW, DPS = 2, SPB = 64 / P;       // SPB: steps per 64-point block
+    constexpr int NORM4_OFF = L::EBUF_OFF;                    // [4 ring][4 waves][64] floats, in the (unused) E buffers
+    static_assert(2 * L::EBUF_ONE_B >= 4 * 4 * 64 * 4, "norm ring does not fit the E buffers");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sm = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int my_pt = (wave * TPW) / RT, my_t0 = (wave * TPW) % RT;
+
+    const int per_problem = a.row_blocks * a.col_splits;
+    const int problem = a.problem_base + (int)blockIdx.x / per_problem;
+    const int rem = (int)blockIdx.x - (problem - a.problem_base) * per_problem;
+    const int rb = a.sp_major ? rem % a.row_blocks : rem / a.col_splits;
+    const int sp = a.sp_major ? rem / a.row_blocks : rem - rb * a.col_splits;
+    const int i0 = rb * 16 * RT;
+    const long long bid = (long long)a.sums_base + blockIdx.x;
+
+    const bf16* rows = reinterpret_cast<const bf16*>(a.cols[problem]) + (long long)a.row_offset * DPAD;
+    const bf16* rows_lo = SPLIT ? reinterpret_cast<const bf16*>(a.cols_lo[problem]) + (long long)a.row_offset * DPAD : rows;
+    const float* rnorm = a.cnorm[problem] + a.row_offset;
+    h16x8_t zreg[RT][KB], zlo[SPLIT ? RT : 1][SPLIT ? KB : 1];            // rotated tile order, see mmd_pipe_kernel
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-        float* grow = a.wg_grad + ((long long)sp * a.n_rows_pad + i0 + 16 * t + i16) * DPAD + wave * SW + 4 * g;
+        const int row = i0 + 16 * ((t + my_t0) % RT) + i16;
+        const bf16* zp = rows + (long long)row * DPAD + wave * SW + 8 * g;
+        const bf16* zl = rows_lo + (long long)row * DPAD + wave * SW + 8 * g;
 #pragma unroll
-        for (int db = 0; db < NI; ++db) *reinterpret_cast<f32x4*>(grow + 16 * db) = acc[db][t];
+        for (int s = 0; s < KB; ++s) {
+            if (row < a.n_rows) zreg[t][s] = *reinterpret_cast<const h16x8_t*>(zp + 32 * s);
+            else zreg[t][s] = h16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (SPLIT) {
+                if (row < a.n_rows) zlo[t][s] = *reinterpret_cast<const h16x8_t*>(zl + 32 * s);
+                else zlo[t][s] = h16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
     }
+    const float gram_unscale2 = SPLIT ? 2.f * split_scales(*a.split_amax).inv_s2 : 2.f;
+    bool my_valid[TPW];
+    float rn[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int my_row = i0 + 16 * (my_t0 + j) + i16;
+        my_valid[j] = my_row < a.n_rows;
+        rn[j] = my_valid[j] ? rnorm[my_row] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int s = 0; s < KB; ++s) {
+            asm volatile("" : "+v"(zreg[t][s]));
+            if constexpr (SPLIT) asm volatile("" : "+v"(zlo[t][s]));
+        }
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) asm volatile("" : "+v"(rn[j]));
+
+    // steps of P points.  Problem 0 (z rows): both column sets.  Problem 1 (y rows): the priors -- all of them, or (sym)
+    // the 64-point blocks J of the symmetric enumeration of mmd.hip, block pairs other than the diagonal weighted 2
+    const int nS = a.tiles_per_set / PT;
+    const int nJ = nS / SPB;
+    const bool sym = problem == 1 && a.sym;
+    const int blkI = (a.row_offset >> 6) + rb;
+    const int symA = (blkI + 1) >> 1;
+    const int symM = symA + 1 + ((nJ - 1 - blkI) >> 1);
+    const long long total = problem == 0 ? 2ll * nS : (sym ? (long long)symM * SPB : (long long)nS);
+    const long long base = (problem == 0 || sym) ? 0 : nS;
+    const int sb = (int)(base + sp * total / a.col_splits);
+    const int se = (int)(base + (sp + 1) * total / a.col_splits);
+    const int nsteps = se - sb;
+
+    const int dma_r = lane >> 2, dma_c = (lane & 3) ^ (2 * ((lane >> 4) & 1));
+    const unsigned dma_voff = (unsigned)(dma_r * DPAD + 8 * dma_c) * 2u;
+    const unsigned dma_voff_b = SPLIT ? dma_voff + (unsigned)(reinterpret_cast<const char*>(a.cols_lo[0]) - reinterpret_cast<const char*>(a.cols[0])) - 1024u
+                                      : dma_voff + 16u * DPAD * 2u - 1024u;
+    const int gram_off = 16 * (4 * i16 + (g ^ (2 * ((i16 >> 2) & 1))));
+
+    struct Meta { int set, p0; float w; };
+    auto step_meta = [&](int v) -> Meta {
+        const int u = v < se ? v : se - 1;
+        if (sym) {
+            const int blk = u / SPB, sub = u - blk * SPB;
+            const int J = blk < symA ? ((blkI + 1) & 1) + 2 * blk : (blk == symA ? blkI : blkI + 2 * (blk - symA));
+            return Meta{1, J * 64 + sub * P, J != blkI ? 2.f : 1.f};
+        }
+        const int set = u >= nS ? 1 : 0;
+        return Meta{set, (u - (set ? nS : 0)) * P, 1.f};
+    };
+    auto xbuf_byte = [&](int b) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
+    // all DMA of one step: its norms into ring slot `ring`; its feature blocks one by one (dma_block)
+    struct Src { const bf16* x; const float* nrm; };
+    auto step_src = [&](int v) -> Src {
+        const Meta m = step_meta(v);
+        const unsigned off = (unsigned)m.p0 * (unsigned)DPAD + (unsigned)(wave * SW);
+        return Src{reinterpret_cast<const bf16*>(a.cols[m.set]) + off, a.cnorm[m.set] + m.p0};
+    };
+    auto stage_norms = [&](const Src& X, int ring) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(NORM4_OFF + (ring * 4 + wave) * 64 * 4));
+        dma4(uniform_ptr(X.nrm), (unsigned)lane * 4u, dst);
+    };
+    auto dma_block = [&](const Src& X, int b, int s) {
+        dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, dma_voff_b, smem_byte + xbuf_byte(b) + 2048u * s);
+    };
+
+    f32x4 S[PT][RT], own[TPW];
+    auto xch_write = [&](int xbuf) {
+        char* xb = sm + L::XCH_OFF + xbuf * L::XCH_ONE_B + lane * 16;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                if (pt == 0 && t < TPW) { own[t] = S[0][t]; continue; }
+                const int q = RT * ((pt + my_pt) % PT) + (t + my_t0) % RT;
+                const int owner = q / TPW;
+                *reinterpret_cast<f32x4*>(xb + (q * 3 + ((wave - owner - 1) & 3)) * 1024) = S[pt][t];
+            }
+    };
+    double sum0 = 0.0, sum1 = 0.0;
+
+    // One interval.  Tile in buffer b: partial Gram into S, each feature block refilled with step Xr behind its matrix
+    // instructions (norms of Xr into ring slot ring_r).  WITH_E: the tile whose partials sit in exchange buffer xbuf
+    // (own partial in `own`, norms in ring slot ring_e, meta m) is finished between them.
+    // DMA in flight on entry: the 1 + DPS KB instructions of the tile in the OTHER buffer; everything older has to land.
+    auto front = [&](auto with_e_tag, int b, const Src& Xr, int ring_r, int xbuf, int ring_e, const Meta& m) {
+        constexpr bool WITH_E = decltype(with_e_tag)::value;
+        const char* xs = sm + xbuf_byte(b);
+        f32x4 part[TPW][3], cn;
+        if constexpr (WITH_E) {
+            const f32x4* xb = reinterpret_cast<const f32x4*>(sm + L::XCH_OFF + xbuf * L::XCH_ONE_B);
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                for (int w = 0; w < 3; ++w) part[j][w] = xb[((wave * TPW + j) * 3 + w) * 64 + lane];
+            cn = *reinterpret_cast<const f32x4*>(sm + NORM4_OFF + ((ring_e * 4 + wave) * 64 + 16 * my_pt + 4 * g) * 4);
+        }
+        constexpr int GD = KB < TVAE_PIPE_GD ? KB : TVAE_PIPE_GD;
+        h16x8_t ab[KB][PT], al[SPLIT ? KB : 1][PT];
+        auto rd = [&](int sr) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                if constexpr (SPLIT) {
+                    ab[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 2048 * sr);
+                    al[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 2048 * sr + 1024);
+                } else {
+                    const int piece = PT * sr + ((pt + my_pt) & (PT - 1));
+                    ab[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 1024 * piece);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // hold the reads ahead of the previous k-steps' matrix instructions
+        };
+        float tt[NE], q[NE];
+        auto e_slice = [&](int s) {
+            constexpr int FIN = KB > 1 ? KB - 2 : 0;
+            if (s == 0) {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) {
+                    const f32x4 sv = ((own[j] + part[j][0]) + part[j][1]) + part[j][2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tt[4 * j + r] = fmaxf((cn[r] + rn[j] - gram_unscale2 * sv[r]) * a.inv_d2, 0.f);
+                }
+            }
+#pragma unroll
+            for (int el = 0; el < NE; ++el) {
+                if (el * (FIN + 1) / NE != s) continue;
+                const int j = el >> 2, r = el & 3;
+                const EQ pl = em1_split(tt[el]);
+                const float ex = __expf(-tt[el]) - 1.f;
+                const bool big = tt[el] >= EM1_POLY_MAX;
+                const bool ok = my_valid[j] && (m.p0 + 16 * my_pt + 4 * g + r < a.n_cols);
+                q[el] = ok ? (big ? ex + tt[el] : pl.q) : 0.f;
+            }
+            if (s != FIN) return;
+            float qs = 0.f;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) qs += (q[4 * j] + q[4 * j + 1]) + (q[4 * j + 2] + q[4 * j + 3]);
+            sum0 += (double)(m.set ? 0.f : qs);
+            sum1 += (double)(m.set ? m.w * qs : 0.f);
+        };
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        wait_vmcnt_n(1 + DPS * KB);
+#pragma unroll
+        for (int s = 0; s < GD; ++s) rd(s);
+        stage_norms(Xr, ring_r);
+#pragma unroll
+        for (int s = 0; s < KB; ++s) {
+            if (s + GD < KB) rd(s + GD);
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(ab[s][pt], zreg[t][s], s == 0 ? zero : S[pt][t]);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(ab[s][pt], zlo[t][s], S[pt][t]);
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(al[s][pt], zreg[t][s], S[pt][t]);
+            }
+            if constexpr (WITH_E) e_slice(s);
+            // the MFMAs of block s are issued (their operand reads have completed) before its refill
+            __builtin_amdgcn_sched_barrier(0);
+            dma_block(Xr, b, s);
+        }
+    };
+
+    if (nsteps > 0) {
+        {
+            const Src X0 = step_src(sb), X1 = step_src(sb + 1), X2 = step_src(sb + 2);
+            stage_norms(X0, 0);
+#pragma unroll
+            for (int s = 0; s < KB; ++s) dma_block(X0, 0, s);
+            stage_norms(X1, 1);
+#pragma unroll
+            for (int s = 0; s < KB; ++s) dma_block(X1, 1, s);
+            front(std::false_type{}, 0, X2, 2, 0, 0, Meta{0, 0, 1.f});
+            xch_write(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        for (int k = 0; k < nsteps; ++k) {
+            const int cur = k & 1, nxt = cur ^ 1;
+            const Meta m = step_meta(sb + k);
+            const Src Xr = step_src(sb + k + 3);
+            front(std::true_type{}, nxt, Xr, (k + 3) & 3, cur, k & 3, m);
+            xch_write(nxt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    wait_vmcnt<0>();
+
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(sm + L::XCH_OFF);
+    const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
+    if (lane == 0) { red[wave * 2 + 0] = w0; red[wave * 2 + 1] = w1; }
+    __syncthreads();
+    if (tid == 0) {
+        a.wg_sums[2 * bid + 0] = (red[0] + red[2]) + (red[4] + red[6]);
+        a.wg_sums[2 * bid + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+
+template <int KB, bool SPLIT>
+int launch_pipe_sum(const MmdArgs& a, int nblocks, hipStream_t s) {
+    constexpr int lds_bytes = PipeLds<KB, SPLIT>::BYTES;
+    static PerDeviceOnce once;
+    TVAE_CHECK_HIP(per_device_once(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_pipe_sum_kernel<KB, SPLIT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    }));
+    hipLaunchKernelGGL((mmd_pipe_sum_kernel<KB, SPLIT>), dim3(nblocks), dim3(256), lds_bytes, s, a);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
 }
 
 template <int KB, bool SPLIT>
@@ -478,21 +894,21 @@ int launch_pipe(const MmdArgs& a, int nblocks, hipStream_t s) {
 }
 
 template <bool SPLIT>
-int launch_pipe_shape(int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
+int launch_pipe_shape(bool grad, int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
     switch (kb) {
-        case 2: return launch_pipe<2, SPLIT>(a, nblocks, s);
-        case 3: return launch_pipe<3, SPLIT>(a, nblocks, s);
-        case 4: return launch_pipe<4, SPLIT>(a, nblocks, s);
-        case 5: return launch_pipe<5, SPLIT>(a, nblocks, s);
-        case 6: return launch_pipe<6, SPLIT>(a, nblocks, s);
+        case 2: return grad ? launch_pipe<2, SPLIT>(a, nblocks, s) : launch_pipe_sum<2, SPLIT>(a, nblocks, s);
+        case 3: return grad ? launch_pipe<3, SPLIT>(a, nblocks, s) : launch_pipe_sum<3, SPLIT>(a, nblocks, s);
+        case 4: return grad ? launch_pipe<4, SPLIT>(a, nblocks, s) : launch_pipe_sum<4, SPLIT>(a, nblocks, s);
+        case 5: return grad ? launch_pipe<5, SPLIT>(a, nblocks, s) : launch_pipe_sum<5, SPLIT>(a, nblocks, s);
+        case 6: return grad ? launch_pipe<6, SPLIT>(a, nblocks, s) : launch_pipe_sum<6, SPLIT>(a, nblocks, s);
     }
     return fail(TVAE_ERR_ARG, "mmd: no pipelined kernel for %d feature blocks", kb);
 }
 
 }  // namespace
 
-int launch_mmd_pipe(bool split, int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
-    return split ? launch_pipe_shape<true>(kb, a, nblocks, s) : launch_pipe_shape<false>(kb, a, nblocks, s);
+int launch_mmd_pipe(bool grad, bool split, int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
+    return split ? launch_pipe_shape<true>(grad, kb, a, nblocks, s) : launch_pipe_shape<false>(grad, kb, a, nblocks, s);
 }
 
 }  // namespace tvae
