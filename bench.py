@@ -37,7 +37,8 @@ CONFIGS = {
     "cfg5": (65536, 1, 1024, 1, 1024, 5, "configs[4] MMD stress global batch 65536 latent dim 1024"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= vector fp32 peak)
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 dense MFMA peak (~2.5 PFLOP/s)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 / fp16 dense MFMA peak (~2.5 PFLOP/s)
+PEAK_HBM_TBS = 8.0                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 REG_W = 0.5
 
 
@@ -67,13 +68,49 @@ class HipEvents:
         return out
 
 
-def make_vae(d, L, n, device, dtype, scope, world, mmd_dtype=None):
+def mmd_mode(L, mmd_bf16, strict):
+    """The arithmetic the MMD kernels of a (latent width, options) pair run in (transformer_vae_amd/csrc/mmd.hip, mmd_mode)."""
+    if L <= 192 or L > 1024:
+        return "fp32"
+    return "bf16" if mmd_bf16 else ("fp32" if strict else "split")
+
+
+def mmd_roofline(mode, L, achieved, kern_ms, launches, traffic=None):
+    """roofline object of the MMD tile kernels of one call (one gradient launch + one sum-only launch, bracketed by the
+    HIP events of tvae_profile_next_mmd).  `achieved` counts ALGORITHMIC flops, 10 N_rows N D."""
+    pipe = 192 < L <= 768
+    if mode == "split":
+        return {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None, "traffic": traffic,
+                "kernel": ("mmd_pipe_kernel<KB,true> + mmd_pipe_sum_kernel<KB,true>" if pipe else "mmd_bf16_kernel<KB,2,*,true>"),
+                "kernel_ms": kern_ms, "launches_timed": launches,
+                "products_per_fp32_product": 3, "executed_tflops": 3.0 * achieved if achieved else None,
+                "frac_executed": 3.0 * achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None,
+                "peak_note": "fp16 MFMA dense peak (v_mfma_f32_16x16x32_f16 / 32x32x16_f16).  fp32 operands are scaled fp16 pairs hi + lo "
+                             "and every fp32 product is THREE fp16 matrix products (hi*hi + hi*lo + lo*hi), so algorithmic flops top out "
+                             "at peak / 3 = 833 TFLOP/s: `frac` is algorithmic / peak, `frac_executed` counts the three products "
+                             "(upper bound: the symmetric y-y launch executes half of its share)"}
+    if mode == "bf16":
+        return {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None, "traffic": None,
+                "kernel": ("mmd_pipe_kernel<KB,false> + mmd_pipe_sum_kernel<KB,false>" if pipe else "mmd_bf16_kernel"),
+                "kernel_ms": kern_ms, "launches_timed": launches,
+                "peak_note": "bf16 MFMA (v_mfma_f32_16x16x32_bf16) dense peak; opt-in mode, latents and prior rounded to bf16; "
+                             "algorithmic flops (one matrix product per product)"}
+    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, "traffic": traffic,
+            "kernel": "mmd_tile_kernel", "kernel_ms": kern_ms, "launches_timed": launches,
+            "peak_note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak; the Gram and gradient products run in exact fp32; "
+                         "algorithmic flops (the symmetric y-y launch executes half of its share)"}
+
+
+def make_vae(d, L, n, device, dtype, scope, world, mmd_dtype=None, strict=False):
     import transformer_vae_amd as amd
     cfg = SimpleNamespace(t5=SimpleNamespace(d_model=d), funnel=SimpleNamespace(d_model=d, layer_norm_eps=1e-9),
                           latent_size=L, n_latent_tokens=n)
     torch.manual_seed(0)      # default nn.Linear / LayerNorm init under seed 0 (SURVEY.md 8d)
     vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](cfg), amd.VAE_DECODER_MODELS[""](cfg), True,
-                                mmd_scope=scope, compensate_ddp_mean=False, mmd_dtype=mmd_dtype)
+                                mmd_scope=scope, compensate_ddp_mean=False, mmd_dtype=mmd_dtype, mmd_strict_fp32=strict)
     return vae.to(device).to(dtype)
 
 
@@ -192,8 +229,19 @@ def side_config(cfg_name, device, graphed):
     torch.cuda.synchronize(device)
     sec = (time.perf_counter() - t0) / steps
     assert h.grad is not None and bool(torch.isfinite(h.grad).all())
-    return {"workload": f"{cfg_name}: {label}", "value": B / sec, "unit": "samples/s", "ms_per_step": sec * 1e3,
-            "steps": steps, "hip_graph": bool(graphed)}
+    res = {"workload": f"{cfg_name}: {label}", "value": B / sec, "unit": "samples/s", "ms_per_step": sec * 1e3,
+           "steps": steps, "hip_graph": bool(graphed)}
+    if cfg_name == "cfg3":
+        # SURVEY.md 8d, algorithmic HBM bytes of one fp32 step: h[:, :n] read + dh[:, :n] written + recon written + G0 read
+        # (4 N d), the zero-fill of dh[:, n:] (B (S - n) d), z written + re-read (~4 N D), the prior read twice (2 N D),
+        # weights and their gradients (4 d D); 4 bytes each
+        nbytes = 4.0 * (4 * N * d + B * (S - n_eff) * d + 4 * N * L + 2 * N * L + 4 * d * L)
+        ach = nbytes / sec / 1e12
+        res["roofline"] = {"bound": "hbm", "bytes": nbytes, "achieved": ach, "peak": PEAK_HBM_TBS, "unit": "TB/s",
+                           "frac": ach / PEAK_HBM_TBS, "traffic": None,
+                           "note": "whole step (all kernels) against the algorithmic bytes of SURVEY.md 8d; "
+                                   "the MMD of this configuration (N = 5 120, D = 77) is matrix-core work inside the same step"}
+    return res
 
 
 def main():
@@ -205,6 +253,8 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--mmd-dtype", default="ref", choices=["ref", "bf16"],
                     help="ref: the reference's promotion (fp32 against its fp32 prior); bf16: opt-in bf16 matrix-core MMD")
+    ap.add_argument("--mmd-strict-fp32", action="store_true",
+                    help="fp32 inputs: keep the fp32-input MFMA kernels instead of the default split-fp16 form (same 1e-5 class)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the bounded cfg1/cfg2/cfg3 runs reported under other_configs (N=1 only)")
@@ -260,7 +310,7 @@ def main():
         torch.cuda.empty_cache()
     mmd_bf16 = args.mmd_dtype == "bf16"
     vae = make_vae(d, L, n, device, dtype, "global" if world > 1 else "local", world,
-                   torch.bfloat16 if mmd_bf16 else None)
+                   torch.bfloat16 if mmd_bf16 else None, args.mmd_strict_fp32)
     # rank r takes rows [r B/R, (r+1) B/R) of the SAME global tensors (generated on every rank from
     # the same seeds, sliced, the rest released), so reg_loss is the same number at every N -- a built-in check
     # of the sharded path against the single-GPU one.
@@ -319,76 +369,70 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = B / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel (mmd_tile_kernel), measured live with HIP events ----
+    # ---- roofline of the dominant kernels (the MMD tile kernels of the call), measured live with HIP events ----
     tile_ms = events.durations_ms()
     kern_ms = float(np.mean(tile_ms)) if tile_ms else float("nan")
     # algorithmic flops of one launch on this rank: 10 * N_local_rows * N * D (3 Grams fwd
     # 6 N^2 D + 2 gradient products 4 N^2 D, no symmetry credit, recompute not counted)
     flops = 10.0 * Nl * N * L
     achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms == kern_ms else None
+    mode = mmd_mode(L, mmd_bf16 or args.dtype == "bf16", args.mmd_strict_fp32)
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(f"{args.config}_{args.dtype}_gpus{world}")
+            traffic = json.load(open(tfile)).get(f"{args.config}_{args.dtype}_{mode}_gpus{world}")
         except Exception:
             traffic = None
-    bf16_tiles = mmd_bf16 and L > 192
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16_tiles else PEAK_F32_MFMA_TFLOPS
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": (achieved / peak) if achieved else None, "traffic": None if mmd_bf16 else traffic,
-                "kernel": "mmd_bf16_kernel" if bf16_tiles else "mmd_tile_kernel", "kernel_ms": kern_ms,
-                "launches_timed": len(tile_ms),
-                "peak_note": ("bf16 MFMA (v_mfma_f32_16x16x32_bf16) dense peak; opt-in mode, latents and prior rounded to bf16"
-                              if bf16_tiles else
-                              "fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak; the Gram and gradient products run in exact fp32")}
+    roofline = mmd_roofline(mode, L, achieved, kern_ms, len(tile_ms), traffic if mode != "bf16" else None)
 
     line = {
         "metric": "bottleneck+MMD fwd+bwd samples/sec", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": ("f32" if args.dtype == "fp32" else "bf16") + ("+bf16-mmd" if mmd_bf16 else ""), "data": "synthetic",
+        "dtype": ("f32" if args.dtype == "fp32" else "bf16") + ("+bf16-mmd" if mmd_bf16 else "") +
+                 (" (MMD products as split fp16 pairs, fp32 accumulate)" if mode == "split" else ""), "data": "synthetic",
         "config": {"workload": f"{args.config}: {label}", "global_batch": B, "seq_len": S, "d_model": d,
                    "n_latent_tokens": n, "latent_size": L, "mmd_rows": N,
                    "parallelism": f"row-sharded global-batch MMD x{world}" if world > 1 else "single GPU"},
         "reg_loss": reg, "roofline": roofline,
     }
-    if rank == 0 and world == 1 and others is not None and not mmd_bf16 and args.dtype == "fp32" and L > 192:
-        # the opt-in bf16 matrix-core MMD (EncoderDecoderVAE(mmd_dtype=torch.bfloat16): latents and prior rounded to
-        # bf16 for the regulariser only, 1e-2 parity class) on the SAME inputs -- reported beside the exact-fp32
-        # headline, never instead of it
-        try:
-            vae16 = make_vae(d, L, n, device, dtype, "local", 1, torch.bfloat16)
-            p16 = list(vae16.parameters())
-            ev16 = HipEvents()
+    if rank == 0 and world == 1 and others is not None and not mmd_bf16 and args.dtype == "fp32" and 192 < L <= 1024:
+        # the other two arithmetic modes of the MMD on the SAME inputs, reported beside the headline, never instead of it:
+        #   strict fp32 (mmd_strict_fp32=True: fp32-input MFMA, the round-1 headline) and the opt-in bf16 matrix-core MMD
+        #   (mmd_dtype=torch.bfloat16: latents and prior rounded to bf16 for the regulariser only, 1e-2 parity class)
+        for tag, kw, m2 in ((("strict fp32 MMD (fp32-input MFMA)", dict(strict=True), "fp32"),) if not args.mmd_strict_fp32 else ()) + \
+                (("opt-in bf16 matrix-core MMD", dict(mmd_dtype=torch.bfloat16), "bf16"),):
+            try:
+                vae2 = make_vae(d, L, n, device, dtype, "local", 1, **kw)
+                p2 = list(vae2.parameters())
+                ev2 = HipEvents()
 
-            def step16(timed):
-                h.grad = None
-                for p in p16:
-                    p.grad = None
-                if timed:
-                    lib.tvae_profile_next_mmd(*ev16.new_pair())
-                o = vae16(input_encoding=h, true_samples=prior)
-                (o.reg_loss * REG_W + (o.reconstructed_encoding * g0).sum()).backward()
-                return o
+                def step2(timed):
+                    h.grad = None
+                    for p in p2:
+                        p.grad = None
+                    if timed:
+                        lib.tvae_profile_next_mmd(*ev2.new_pair())
+                    o = vae2(input_encoding=h, true_samples=prior)
+                    (o.reg_loss * REG_W + (o.reconstructed_encoding * g0).sum()).backward()
+                    return o
 
-            step16(False)
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                o16 = step16(True)
-            fence()
-            sec16 = (time.perf_counter() - t1) / args.steps
-            k16 = float(np.mean(ev16.durations_ms()))
-            a16 = flops / (k16 * 1e-3) / 1e12
-            others.append({"workload": f"{args.config}: {label} -- opt-in bf16 matrix-core MMD", "value": B / sec16,
-                           "unit": "samples/s", "ms_per_step": sec16 * 1e3, "steps": args.steps, "hip_graph": False,
-                           "dtype": "f32+bf16-mmd", "reg_loss": float(o16.reg_loss.detach()),
-                           "roofline": {"bound": "mfma", "achieved": a16, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": a16 / PEAK_BF16_MFMA_TFLOPS, "kernel": "mmd_bf16_kernel", "kernel_ms": k16}})
-            del vae16, p16
-        except Exception as e:
-            others.append({"workload": f"{args.config} bf16 MMD", "hip_graph": False, "value": None, "error": repr(e)[:200]})
+                step2(False)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    o2 = step2(True)
+                fence()
+                sec2 = (time.perf_counter() - t1) / args.steps
+                k2 = float(np.mean(ev2.durations_ms()))
+                others.append({"workload": f"{args.config}: {label} -- {tag}", "value": B / sec2,
+                               "unit": "samples/s", "ms_per_step": sec2 * 1e3, "steps": args.steps, "hip_graph": False,
+                               "dtype": "f32" if m2 == "fp32" else "f32+bf16-mmd", "reg_loss": float(o2.reg_loss.detach()),
+                               "roofline": mmd_roofline(m2, L, flops / (k2 * 1e-3) / 1e12, k2, args.steps)})
+                del vae2, p2
+            except Exception as e:
+                others.append({"workload": f"{args.config} {tag}", "hip_graph": False, "value": None, "error": repr(e)[:200]})
     if rank == 0:
         if others is not None:
             line["other_configs"] = others

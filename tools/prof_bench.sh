@@ -9,5 +9,5 @@ B=$GRAFT_REPO_ROOT/bench.py
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $B "$@" --no-cpu-baseline --no-side-configs > $OUT/trace.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $B "$@" --no-cpu-baseline --no-side-configs > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $B "$@" --no-cpu-baseline --no-side-configs > $OUT/pmc_write.log 2>&1
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $B "$@" --no-cpu-baseline --no-side-configs > $OUT/pmc_sq.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $B "$@" --no-cpu-baseline --no-side-configs > $OUT/pmc_sq.log 2>&1
 tail -1 $OUT/trace.log | cut -c1-200

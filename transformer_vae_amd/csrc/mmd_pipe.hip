@@ -679,17 +679,28 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
     for (int j = 0; j < TPW; ++j) asm volatile("" : "+v"(rn[j]));
 
     // steps of P points.  Problem 0 (z rows): both column sets.  Problem 1 (y rows): the priors -- all of them, or (sym)
-    // the 64-point blocks J of the symmetric enumeration of mmd.hip, block pairs other than the diagonal weighted 2
+    // each unordered pair of 64-point blocks once, pairs other than the diagonal weighted 2: row block I takes the
+    // column blocks J < I of the parity of I + 1, J = I, and J > I of the parity of I (mmd.hip).  Split sp owns the
+    // column blocks [sp nJ / cs, (sp + 1) nJ / cs) and a workgroup walks those of ITS blocks J that fall in the range:
+    // the workgroups of one split (neighbours in launch order under sp_major) then stream the same ~1 / cs of the
+    // priors, which L2 and the Infinity Cache hold, instead of 3 840 different halves of all of them (cfg4 size:
+    // 1.1e12 B per launch at the fabric, the kernel ran at its pace).
     const int nS = a.tiles_per_set / PT;
     const int nJ = nS / SPB;
     const bool sym = problem == 1 && a.sym;
     const int blkI = (a.row_offset >> 6) + rb;
-    const int symA = (blkI + 1) >> 1;
-    const int symM = symA + 1 + ((nJ - 1 - blkI) >> 1);
-    const long long total = problem == 0 ? 2ll * nS : (sym ? (long long)symM * SPB : (long long)nS);
-    const long long base = (problem == 0 || sym) ? 0 : nS;
-    const int sb = (int)(base + sp * total / a.col_splits);
-    const int se = (int)(base + (sp + 1) * total / a.col_splits);
+    const int jlo = (int)((long long)sp * nJ / a.col_splits), jhi = (int)((long long)(sp + 1) * nJ / a.col_splits);
+    const int aend = blkI < jhi ? blkI : jhi;                                  // part A: J in [jlo, aend), parity of I + 1
+    const int ja0 = jlo + ((jlo ^ (blkI + 1)) & 1);
+    const int nA = aend > ja0 ? (aend - ja0 + 1) >> 1 : 0;
+    const int nB = (blkI >= jlo && blkI < jhi) ? 1 : 0;                        // part B: the diagonal block
+    const int cbeg = blkI + 1 > jlo ? blkI + 1 : jlo;                          // part C: J in [cbeg, jhi), parity of I
+    const int jc0 = cbeg + ((cbeg ^ blkI) & 1);
+    const int nC = jhi > jc0 ? (jhi - jc0 + 1) >> 1 : 0;
+    const long long total = problem == 0 ? 2ll * nS : (long long)nS;
+    const long long base = problem == 0 ? 0 : nS;
+    const int sb = sym ? 0 : (int)(base + sp * total / a.col_splits);
+    const int se = sym ? (nA + nB + nC) * SPB : (int)(base + (sp + 1) * total / a.col_splits);
     const int nsteps = se - sb;
 
     const int dma_r = lane >> 2, dma_c = (lane & 3) ^ (2 * ((lane >> 4) & 1));
@@ -703,7 +714,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
         const int u = v < se ? v : se - 1;
         if (sym) {
             const int blk = u / SPB, sub = u - blk * SPB;
-            const int J = blk < symA ? ((blkI + 1) & 1) + 2 * blk : (blk == symA ? blkI : blkI + 2 * (blk - symA));
+            const int J = blk < nA ? ja0 + 2 * blk : (blk < nA + nB ? blkI : jc0 + 2 * (blk - nA - nB));
             return Meta{1, J * 64 + sub * P, J != blkI ? 2.f : 1.f};
         }
         const int set = u >= nS ? 1 : 0;
