@@ -78,3 +78,115 @@ def test_sharded_global_mmd_equals_single_process(compensate):
     assert abs(reg - ref) <= 1e-6 * abs(ref)
     gref = 0.5 * (n / B) * orc.mmd_grad_latent_rows(z64, z64, y64) * (world if compensate else 1)
     assert np.abs(grad - gref).max() <= 1e-6 * np.abs(gref).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# DistributedDataParallel: DDP AVERAGES parameter gradients over ranks; with compensate_ddp_mean (the default under
+# global scope) the averaged gradients must equal those of ONE process holding the global batch (trainer.py:265-266
+# is the reference's only multi-GPU line; it never measured a curve).
+# ---------------------------------------------------------------------------------------------------------------
+class _TinyEncoder(torch.nn.Module):
+    def __init__(self, d, D):
+        super().__init__()
+        self.lin = torch.nn.Linear(d, D)
+
+    def forward(self, h):
+        return torch.tanh(self.lin(h))
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from transformer_vae_amd.distributed import sharded_mmd_reg_loss
+        B, n, d, D = 4, 3, 5, 7                 # per rank
+        torch.manual_seed(3)
+        enc = _TinyEncoder(d, D)
+        ddp = DDP(enc)
+        rs = np.random.RandomState(200 + rank)
+        h = torch.from_numpy(rs.standard_normal((B * n, d)).astype(np.float32))
+        y = torch.from_numpy(rs.standard_normal((B * n, D)).astype(np.float32))
+        z = ddp(h)
+        reg = sharded_mmd_reg_loss(z, y, B, n, None, True, OracleRowBlock.apply)     # compensate_ddp_mean = True
+        reg.backward()                                                               # DDP all-reduces and divides by world
+        hs, ys = [torch.empty_like(h) for _ in range(world)], [torch.empty_like(y) for _ in range(world)]
+        dist.all_gather(hs, h)
+        dist.all_gather(ys, y)
+        if rank == 0:
+            out.put((float(reg), enc.lin.weight.grad.numpy(), enc.lin.bias.grad.numpy(), torch.cat(hs).numpy(), torch.cat(ys).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_averaged_parameter_grads_equal_the_global_batch_grads():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    reg, gw, gb, h_all, y_all = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # one process, the global batch: autograd through tanh(Linear) with the oracle's latent gradient
+    B, n = 4 * world, 3
+    torch.manual_seed(3)
+    enc = _TinyEncoder(5, 7).double()
+    z = enc(torch.from_numpy(h_all).double())
+    ref = orc.mmd_gram(y_all.astype(np.float64), z.detach().numpy()) * n / B
+    gz = (n / B) * orc.mmd_grad_latent_rows(z.detach().numpy(), z.detach().numpy(), y_all.astype(np.float64))
+    z.backward(torch.from_numpy(gz))
+    assert abs(reg - ref) <= 1e-6 * abs(ref)
+    assert np.abs(gw - enc.lin.weight.grad.numpy()).max() <= 2e-6 * np.abs(enc.lin.weight.grad.numpy()).max()
+    assert np.abs(gb - enc.lin.bias.grad.numpy()).max() <= 2e-6 * np.abs(enc.lin.bias.grad.numpy()).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Global scope draws its prior per rank: the reference launcher seeds all ranks alike (train.py:391), so the default
+# generator would make the gathered prior R copies of one block.
+# ---------------------------------------------------------------------------------------------------------------
+def _prior_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        import transformer_vae_amd as amd
+        cfg = SimpleNamespace(t5=SimpleNamespace(d_model=8), funnel=SimpleNamespace(d_model=8, layer_norm_eps=1e-9),
+                              latent_size=3, n_latent_tokens=2)
+        torch.manual_seed(11)                                   # every rank alike, as the reference launcher
+        mk = lambda: amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](cfg), amd.VAE_DECODER_MODELS[""](cfg), True, mmd_scope="global")
+        cpu = torch.device("cpu")
+        a = mk()
+        own1, own2 = a._draw_prior((4, 3), cpu), a._draw_prior((4, 3), cpu)
+        b = mk()
+        all1, all2 = b._draw_prior_all_ranks((4, 3), cpu), b._draw_prior_all_ranks((4, 3), cpu)
+        blocks = [torch.empty_like(own1) for _ in range(world)]
+        dist.all_gather(blocks, own1)
+        out.put((rank, own1.numpy(), own2.numpy(), all1.numpy(), all2.numpy(), torch.cat(blocks).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_scope_prior_streams_differ_per_rank_and_replay_everywhere():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prior_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, o0, o0b, a0, a0b, g0), (_, o1, o1b, a1, a1b, g1) = res
+    assert not np.array_equal(o0, o1) and not np.array_equal(o0, o0b)          # ranks differ, draws advance
+    assert np.array_equal(g0, np.concatenate([o0, o1])) and np.array_equal(g0, g1)
+    # the all-rank replay is the gathered prior, on every rank, draw after draw: no all-gather needed
+    assert np.array_equal(a0, g0) and np.array_equal(a1, g0)
+    assert np.array_equal(a0b, np.concatenate([o0b, o1b])) and np.array_equal(a1b, a0b)

@@ -972,3 +972,38 @@ def test_mmd_gradient_at_scale_sampled_rows(N, D, dtype):
     got = zt.grad.float().cpu().numpy()[rows]
     tol = F32_TOL if dtype == torch.float32 else BF16_TOL
     assert np.abs(got - gref).max() <= tol * np.abs(gref).max(), (np.abs(got - gref).max(), np.abs(gref).max())
+
+
+def test_no_grad_runs_the_forward_only_plan(monkeypatch):
+    """Under torch.no_grad() (evaluation, prediction) needs_input_grad is still True inside Function.forward: the
+    wrappers pass the grad mode along, so that the MMD runs its sum-only plan -- no gradient slabs, no dz."""
+    from transformer_vae_amd import functional as F, _lib
+    lib = _lib.lib()
+    N, D = 4096, 512
+    gen = torch.Generator(device=dev()).manual_seed(5)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev())).requires_grad_(True)
+    y = torch.randn((N, D), generator=gen, device=dev())
+    sizes = []
+    real = F._workspace
+    monkeypatch.setattr(F, "_workspace", lambda nbytes, device: (sizes.append(int(nbytes)), real(nbytes, device))[1])
+    with torch.no_grad():
+        l0 = F.mmd_reg_loss(z, y, 8, N // 8)
+    fwd_only = lib.tvae_mmd_workspace_bytes_for(N, N, D, 0, _lib.TVAE_F32)
+    with_grad = lib.tvae_mmd_workspace_bytes_for(N, N, D, 1, _lib.TVAE_F32)
+    assert sizes == [fwd_only] and fwd_only < with_grad
+    sizes.clear()
+    l1 = F.mmd_reg_loss(z, y, 8, N // 8)
+    assert sizes == [with_grad]
+    assert not l0.requires_grad and l1.requires_grad
+    assert abs(float(l0) - float(l1)) <= 1e-6 * abs(float(l1))
+    # the fused module step too
+    _, params, _, _ = orc.synth_inputs(2, 2, 64, 5, 300, 1, "")
+    vae = build_vae(64, 300, 5, "", params)
+    h = torch.randn((32, 7, 64), generator=gen, device=dev()).requires_grad_(True)
+    pr = torch.randn((160, 300), generator=gen, device=dev())
+    sizes.clear()
+    with torch.no_grad():
+        out = vae(input_encoding=h, true_samples=pr)
+    assert lib.tvae_mmd_workspace_bytes_for(160, 160, 300, 0, _lib.TVAE_F32) in sizes
+    assert lib.tvae_mmd_workspace_bytes_for(160, 160, 300, 1, _lib.TVAE_F32) not in sizes
+    assert not out.reg_loss.requires_grad

@@ -236,21 +236,37 @@ class EncoderDecoderVAE(nn.Module):
         if not self._global_scope_active():
             return torch.randn(size, device=device)
         import torch.distributed as dist
-        key = str(device)
+        return torch.randn(size, device=device, generator=self._rank_generator(dist.get_rank(self.process_group), device))
+
+    def _rank_generator(self, rank, device):
+        key = (str(device), int(rank))
         gen = self._prior_generators.get(key)
         if gen is None:
             gen = torch.Generator(device=device)
-            gen.manual_seed(torch.initial_seed() + 1 + dist.get_rank(self.process_group))
+            gen.manual_seed(torch.initial_seed() + 1 + int(rank))
             self._prior_generators[key] = gen
-        return torch.randn(size, device=device, generator=gen)
+        return gen
+
+    def _draw_prior_all_ranks(self, size_local, device):
+        """Global scope, no caller prior: every rank replays the streams of ALL ranks (same seeds, advanced in step on
+        every rank), so the (N, D) prior exists everywhere without an all-gather.  Block r is exactly what rank r's
+        ``_draw_prior`` would have drawn."""
+        import torch.distributed as dist
+        world = dist.get_world_size(self.process_group)
+        return torch.cat([torch.randn(size_local, device=device, generator=self._rank_generator(r, device))
+                          for r in range(world)], dim=0)
 
     def _regularliser_loss(self, latent, batch_size=None, n_latents_per_batch=None, true_samples=None):
         """The reference's one-argument form, ``_regularliser_loss(latent)`` (autoencoders.py:134-136), returns the
         unscaled MMD(prior, latent).  With ``batch_size`` and ``n_latents_per_batch`` the result is
         MMD / batch_size * n_latents (:112) -- the scaling folded into the kernel's output scale, which is how
         ``forward`` calls it."""
+        prior_all = None
         if true_samples is None:
-            true_samples = self._draw_prior(latent.size(), latent.device)
+            if self._global_scope_active() and batch_size is not None and n_latents_per_batch is not None and latent.numel():
+                prior_all = self._draw_prior_all_ranks(latent.size(), latent.device)
+            else:
+                true_samples = self._draw_prior(latent.size(), latent.device)
         else:
             true_samples = true_samples.reshape(latent.shape).to(latent.device)
         if batch_size is None or n_latents_per_batch is None:
@@ -261,9 +277,11 @@ class EncoderDecoderVAE(nn.Module):
             # the reference takes the mean of empty kernel matrices (:130-131): nan, not an error
             return torch.full((), float("nan"), dtype=torch.float32, device=latent.device)
         if self.mmd_dtype is not None:
-            latent, true_samples = latent.to(self.mmd_dtype), true_samples.to(self.mmd_dtype)
+            latent = latent.to(self.mmd_dtype)
+            true_samples = None if true_samples is None else true_samples.to(self.mmd_dtype)
+            prior_all = None if prior_all is None else prior_all.to(self.mmd_dtype)
         if self._global_scope_active():
             from .distributed import sharded_mmd_reg_loss
             return sharded_mmd_reg_loss(latent, true_samples, batch_size, n_latents_per_batch, self.process_group,
-                                        self.compensate_ddp_mean, strict_fp32=self.mmd_strict_fp32)
+                                        self.compensate_ddp_mean, strict_fp32=self.mmd_strict_fp32, prior_all=prior_all)
         return F.mmd_reg_loss(latent, true_samples, batch_size, n_latents_per_batch, self.mmd_strict_fp32)

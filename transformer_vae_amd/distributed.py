@@ -49,12 +49,15 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
     return x
 
 
-def sharded_mmd_reg_loss(latent2d: torch.Tensor, prior_local: torch.Tensor, batch_size_local: int, n_latents: int,
+def sharded_mmd_reg_loss(latent2d: torch.Tensor, prior_local: Optional[torch.Tensor], batch_size_local: int, n_latents: int,
                          group=None, compensate_ddp_mean: bool = True,
-                         row_block_fn: Optional[Callable] = None, strict_fp32: bool = False) -> torch.Tensor:
+                         row_block_fn: Optional[Callable] = None, strict_fp32: bool = False,
+                         prior_all: Optional[torch.Tensor] = None) -> torch.Tensor:
     """reg_loss of the GLOBAL batch; every rank returns the same value.
 
     latent2d / prior_local: this rank's (N/R, D) rows (equal counts on all ranks).
+    ``prior_all``: the (N, D) prior of ALL ranks in rank order, when every rank can produce it itself (seeded draws:
+    EncoderDecoderVAE under global scope) -- the prior all-gather, half of the bytes on the wire, is then skipped.
     The gradient that flows into ``latent2d`` is d(global reg)/d(local rows), complete.
     ``compensate_ddp_mean``: DDP averages parameter gradients over R ranks while each rank
     holds only its rows' share of the global loss gradient; multiplying the local gradient
@@ -65,8 +68,13 @@ def sharded_mmd_reg_loss(latent2d: torch.Tensor, prior_local: torch.Tensor, batc
     rank = dist.get_rank(group)
     n_local, dim = latent2d.shape
     z_all = all_gather_rows(latent2d.detach(), group)
-    y_all = all_gather_rows(prior_local, group)
     n_total = n_local * world
+    if prior_all is not None:
+        if tuple(prior_all.shape) != (n_total, dim):
+            raise ValueError(f"prior_all must be ({n_total}, {dim}), got {tuple(prior_all.shape)}")
+        y_all = prior_all
+    else:
+        y_all = all_gather_rows(prior_local, group)
     loss_scale, grad_scale = F.mmd_scales(batch_size_local * world, n_latents, n_total, dim)
     if compensate_ddp_mean:
         grad_scale *= world

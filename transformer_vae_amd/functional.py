@@ -202,7 +202,8 @@ class _MMDRegulariser(torch.autograd.Function):
 
     @staticmethod
     @_on_tensor_device
-    def forward(ctx, z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float, strict_fp32: bool = False):
+    def forward(ctx, z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float, strict_fp32: bool = False,
+                grad_enabled: bool = True):
         _require_device(z_all, "MMD regulariser")
         dt = torch.bfloat16 if (z_all.dtype == torch.bfloat16 and y_all.dtype == torch.bfloat16) else torch.float32
         code = _mmd_code(dt, strict_fp32)
@@ -212,7 +213,9 @@ class _MMDRegulariser(torch.autograd.Function):
         if tuple(ya.shape) != (n_total, D):
             raise ValueError(f"prior samples {tuple(ya.shape)} must match latents {(n_total, D)}")
         n_rows = z_rows.shape[0]
-        want_grad = bool(ctx.needs_input_grad[0])
+        # needs_input_grad stays True under torch.no_grad(); the wrappers pass the grad mode they were called in, so that
+        # evaluation steps run the sum-only plan (no gradient slabs, no dz)
+        want_grad = bool(grad_enabled) and bool(ctx.needs_input_grad[0])
         dev = za.device
         lib = _lib.lib()
         ws_bytes = lib.tvae_mmd_workspace_bytes_for(n_total, n_rows, D, int(want_grad), code)
@@ -236,7 +239,7 @@ class _MMDRegulariser(torch.autograd.Function):
     def backward(ctx, g_loss, _g_sums):
         (dz,) = ctx.saved_tensors
         g = (dz.float() * g_loss.float()).to(ctx.z_dtype)
-        return g, None, None, None, None, None, None
+        return g, None, None, None, None, None, None, None
 
 
 class _BottleneckStep(torch.autograd.Function):
@@ -249,7 +252,8 @@ class _BottleneckStep(torch.autograd.Function):
 
     @staticmethod
     @_on_tensor_device
-    def forward(ctx, h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float, strict_fp32: bool = False):
+    def forward(ctx, h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float, strict_fp32: bool = False,
+                grad_enabled: bool = True):
         ctx.set_materialize_grads(False)
         dt = h.dtype
         hc = h if h.stride(2) == 1 else h.contiguous()
@@ -271,7 +275,7 @@ class _BottleneckStep(torch.autograd.Function):
         mdt = torch.bfloat16 if (dt == torch.bfloat16 and prior.dtype == torch.bfloat16) else torch.float32
         za = z.reshape(N, L).to(mdt)
         ya = prior.reshape(N, L).to(mdt).contiguous()
-        want_grad = any(ctx.needs_input_grad[:3])
+        want_grad = bool(grad_enabled) and any(ctx.needs_input_grad[:3])
         loss_scale, grad_scale = mmd_scales(B, n_eff, N, L)
         mcode = _mmd_code(mdt, strict_fp32)
         ws_bytes = lib.tvae_mmd_workspace_bytes_for(N, N, L, int(want_grad), mcode)
@@ -360,7 +364,7 @@ class _BottleneckStep(torch.autograd.Function):
                 _lib.check(lib.tvae_encode_bwd(_ptr(dz), _ptr(z), _ptr(hc), hc.stride(0), hc.stride(1), _ptr(Wc),
                                                _ptr(dh), _ptr(dWe), _ptr(dbe), B, S, n_eff, d, L, code,
                                                _ptr(ws), ws.numel(), stream), "tvae_encode_bwd")
-        return dh, dWe, dbe, dWd, dbd, dgamma, dbeta, None, None, None, None
+        return dh, dWe, dbe, dWd, dbd, dgamma, dbeta, None, None, None, None, None
 
 
 class _Upsample(torch.autograd.Function):
@@ -422,19 +426,20 @@ def mmd_reg_loss(latent2d, prior, batch_size: int, n_latents: int, strict_fp32: 
     """Single-device regulariser: MMD(prior, latent) / batch_size * n_latents, fp32 scalar."""
     n_total, dim = latent2d.shape
     ls, gs = mmd_scales(batch_size, n_latents, n_total, dim)
-    loss, _ = _MMDRegulariser.apply(latent2d, latent2d, prior, 0, ls, gs, bool(strict_fp32))
+    loss, _ = _MMDRegulariser.apply(latent2d, latent2d, prior, 0, ls, gs, bool(strict_fp32), torch.is_grad_enabled())
     return loss
 
 
 def mmd_row_block(z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad_scale: float, strict_fp32: bool = False):
     """Row-sharded building block: returns (local loss share, float64[3] partial sums)."""
     return _MMDRegulariser.apply(z_rows, z_all, y_all, int(row_offset), float(loss_scale), float(grad_scale),
-                                 bool(strict_fp32))
+                                 bool(strict_fp32), torch.is_grad_enabled())
 
 
 def bottleneck_step(h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float, strict_fp32: bool = False):
     """(latent, reconstructed_encoding, reg_loss) of the stock bottleneck as one autograd node."""
-    return _BottleneckStep.apply(h, We, be, Wd, bd, gamma, beta, prior, int(n_tokens), float(eps), bool(strict_fp32))
+    return _BottleneckStep.apply(h, We, be, Wd, bd, gamma, beta, prior, int(n_tokens), float(eps), bool(strict_fp32),
+                                 torch.is_grad_enabled())
 
 
 def upsample(x, stride: int, target_len: int, separate_cls: bool = True, truncate_seq: bool = False):
