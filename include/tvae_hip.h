@@ -175,6 +175,36 @@ int tvae_mmd_fwd_bwd_static(const void* z_all, const void* y_all,
                             void* d_z, double grad_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Small-batch whole step (fp32, stock decoder = Linear + LayerNorm): the path of
+ * EncoderDecoderVAE.forward (autoencoders.py:94-115: encode :21-22, regulariser :110-112 and
+ * :117-136, decode :38-39 and :66-67) and of its autograd, in TWO launches each, for the
+ * reference's own configurations (N = B * n_eff <= 512 latent rows, latent_size <= 128,
+ * d_model <= 2048 and a multiple of 16).  Same arguments and results as the sequence
+ * tvae_encode_fwd -> tvae_mmd_fwd_bwd -> tvae_decode_fwd, resp. tvae_decode_bwd ->
+ * tvae_encode_bwd_sum (to fp32 rounding: the sums run in a different order).
+ *   tvae_small_step_supported  1 when the shape is inside the path
+ *   fwd: prior (N, L) fp32; d_latent_mmd (N, L) out, nullable (no gradient wanted);
+ *        loss_scale / grad_scale as in tvae_mmd_fwd_bwd
+ *   bwd: d_reg device scalar (upstream gradient of reg_loss), nullable together with
+ *        d_latent_mmd; every output pointer is nullable
+ * --------------------------------------------------------------------------------- */
+int tvae_small_step_supported(int64_t B, int64_t n_eff, int64_t d, int64_t L);
+int64_t tvae_small_step_fwd_workspace_bytes(int64_t B, int64_t n_eff, int64_t d, int64_t L);
+int64_t tvae_small_step_bwd_workspace_bytes(int64_t B, int64_t n_eff, int64_t d, int64_t L);
+int tvae_small_step_fwd(const void* h, int64_t h_stride_b, int64_t h_stride_s, const void* We, const void* be,
+                        const void* Wd, const void* bd, const void* gamma, const void* beta, float eps,
+                        const void* prior, int64_t B, int64_t n_eff, int64_t d, int64_t L, int dtype,
+                        void* latent, void* recon, void* pre_norm, float* mean, float* rstd, void* d_latent_mmd,
+                        double* sums3, float* loss, double loss_scale, double grad_scale,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+int tvae_small_step_bwd(const void* d_recon, const float* d_reg, const void* latent, const void* pre_norm,
+                        const float* mean, const float* rstd, const void* gamma, const void* Wd, const void* We,
+                        const void* h, int64_t h_stride_b, int64_t h_stride_s, const void* d_latent_mmd,
+                        void* dh, void* dWe, void* dbe, void* dWd, void* dbd, void* dgamma, void* dbeta,
+                        int64_t B, int64_t S, int64_t n_eff, int64_t d, int64_t L, int dtype,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Next to the path.
  *
  * Upsample of reconstructed_encoding into decoder memory.  Replaces

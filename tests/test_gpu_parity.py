@@ -835,10 +835,13 @@ def test_random_row_blocks_against_fp64_oracle(N, D, lo, hi):
 @pytest.mark.parametrize("B,S,d,n,L,dec,dtype", [(8, 60, 512, 5, 77, "", torch.float32), (70, 30, 768, 5, 77, "no_norm", torch.float32),
                                                  (6, 3, 64, 5, 33, "", torch.float32), (5, 9, 96, 4, 96, "", torch.float32),
                                                  (16, 12, 256, 6, 300, "", torch.bfloat16)])
-def test_fused_step_equals_the_three_separate_nodes(B, S, d, n, L, dec, dtype):
+def test_fused_step_equals_the_three_separate_nodes(B, S, d, n, L, dec, dtype, monkeypatch):
     """EncoderDecoderVAE.forward takes the one-node path for the stock pair; `fuse_step = False` keeps the three
-    autograd nodes.  Same kernels: outputs identical, gradients equal to rounding (one fused multiply-add),
-    including a cotangent on `latent` itself, a frozen input and frozen parameters."""
+    autograd nodes.  Same kernels (the four-launch small-batch path, which has its own test, is switched off here):
+    outputs identical, gradients equal to rounding (one fused multiply-add), including a cotangent on `latent`
+    itself, a frozen input and frozen parameters."""
+    from transformer_vae_amd import functional as F_
+    monkeypatch.setattr(F_, "SMALL_STEP", False)
     h, params, prior, g0 = orc.synth_inputs(B, S, d, n, L, 11, dec)
     n_eff = min(n, S)
     gl = torch.from_numpy(np.random.RandomState(5).standard_normal((B, n_eff, L)).astype(np.float32)).to(dev()) * 1e-3
@@ -873,7 +876,9 @@ def test_fused_step_equals_the_three_separate_nodes(B, S, d, n, L, dec, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_summed_latent_cotangent_entry_point(dtype):
+def test_summed_latent_cotangent_entry_point(dtype, monkeypatch):
+    from transformer_vae_amd import functional as F_
+    monkeypatch.setattr(F_, "SMALL_STEP", False)          # the general one-node path is what this test is about
     """The usual training loss (reconstruction term + w * reg_loss, nothing on `latent` itself) takes
     tvae_encode_bwd_sum in the one-node path: the decoder's and the regulariser's shares are added inside the
     tanh-backward pass.  Same gradients as the three-node path, which adds them with torch, to one rounding."""
@@ -1007,3 +1012,62 @@ def test_no_grad_runs_the_forward_only_plan(monkeypatch):
     assert lib.tvae_mmd_workspace_bytes_for(160, 160, 300, 0, _lib.TVAE_F32) in sizes
     assert lib.tvae_mmd_workspace_bytes_for(160, 160, 300, 1, _lib.TVAE_F32) not in sizes
     assert not out.reg_loss.requires_grad
+
+
+@pytest.mark.parametrize("B,S,d,n,L", [(8, 60, 512, 5, 77), (70, 30, 768, 5, 77), (3, 4, 64, 7, 16), (33, 9, 1024, 3, 128), (5, 9, 2048, 3, 77),
+                                       (101, 5, 256, 5, 64), (1, 1, 16, 1, 1), (64, 8, 1024, 8, 96)])
+def test_small_step_four_launch_path_equals_the_general_path_and_the_oracle(B, S, d, n, L):
+    """csrc/small_step.hip (forward and backward in two launches each, N <= 512 latent rows) against the general
+    kernels on the same inputs and against the fp64 oracle: ragged row counts, even / odd / maximal latent sizes,
+    truncated slices (n > S), reg-only and recon-only backward."""
+    from transformer_vae_amd import functional as F, _lib
+    _, params, _, _ = orc.synth_inputs(2, 2, d, n, L, 1, "")
+    t2n = lambda t: t.detach().double().cpu().numpy()
+    n_eff = min(n, S)
+    N = B * n_eff
+    gen = torch.Generator(device=dev()).manual_seed(B * 1000 + L)
+    h0 = torch.randn((B, S, d), generator=gen, device=dev())
+    prior = torch.randn((N, L), generator=gen, device=dev())
+    g0 = torch.randn((B, n_eff, d), generator=gen, device=dev()) / float(N * d) ** 0.5
+
+    def run(small, reg_w, use_recon):
+        F.SMALL_STEP = small
+        keep_rows, F.SMALL_STEP_MAX_ROWS = F.SMALL_STEP_MAX_ROWS, 512        # the module itself stops at 128 rows (measured crossover)
+        try:
+            vae = build_vae(d, L, n, "", params)
+            h = h0.clone().requires_grad_(True)
+            out = vae(input_encoding=h, true_samples=prior)
+            loss = out.reg_loss * reg_w
+            if use_recon:
+                loss = loss + (out.reconstructed_encoding * g0).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            return out, h.grad, {k: p.grad for k, p in vae.named_parameters()}
+        finally:
+            F.SMALL_STEP = True
+            F.SMALL_STEP_MAX_ROWS = keep_rows
+
+    assert _lib.lib().tvae_small_step_supported(B, n_eff, d, L) == 1
+    for reg_w, use_recon in ((0.5, True), (1.0, False), (0.0, True)):
+        o1, dh1, g1 = run(True, reg_w, use_recon)
+        o0, dh0, g0_ = run(False, reg_w, use_recon)
+        assert relerr(t2n(o1.latent), t2n(o0.latent)) <= 2e-6 and relerr(t2n(o1.reconstructed_encoding), t2n(o0.reconstructed_encoding)) <= 1e-5
+        assert abs(float(o1.reg_loss.detach()) - float(o0.reg_loss.detach())) <= 1e-5 * abs(float(o0.reg_loss.detach())) + 1e-12
+        assert relerr(t2n(dh1), t2n(dh0)) <= 1e-5
+        assert float(dh1[:, n_eff:].abs().max()) == 0.0 if S > n_eff else True
+        for k in g0_:
+            if g0_[k] is None:
+                assert g1[k] is None, k
+            else:
+                assert relerr(t2n(g1[k]), t2n(g0_[k])) <= 2e-5, k
+    # fp64 oracle, whole step
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    vae = build_vae(d, L, n, "", params)
+    fwd = orc.bottleneck_forward(h0.double().cpu().numpy(), p64, n, prior.double().cpu().numpy(), vae.decoder.norm.eps)
+    bwd = orc.bottleneck_backward(h0.double().cpu().numpy(), p64, n, fwd, g0.double().cpu().numpy(), 0.5,
+                                  prior.double().cpu().numpy())
+    o1, dh1, g1 = run(True, 0.5, True)
+    assert relerr(o1.latent.detach().cpu().numpy(), fwd["latent"]) <= F32_TOL
+    assert relerr(o1.reconstructed_encoding.detach().cpu().numpy(), fwd["recon"]) <= F32_TOL
+    assert abs(float(o1.reg_loss.detach()) - fwd["reg_loss"]) <= F32_TOL * abs(fwd["reg_loss"]) + 1e-12
+    assert relerr(dh1.cpu().numpy(), bwd["h"]) <= F32_TOL

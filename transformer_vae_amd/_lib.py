@@ -47,6 +47,17 @@ SIGNATURES = {
     "tvae_slerp": (_int, [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _int, _vp]),
     "tvae_mmd_fwd_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp, _i64, _vp]),
     "tvae_mmd_fwd_bwd_static": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp]),
+    "tvae_small_step_supported": (_int, [_i64] * 4),
+    "tvae_small_step_fwd_workspace_bytes": (_i64, [_i64] * 4),
+    "tvae_small_step_bwd_workspace_bytes": (_i64, [_i64] * 4),
+    # h, stride_b, stride_s, We, be, Wd, bd, gamma, beta, eps, prior, B, n_eff, d, L, dtype, latent, recon, pre, mean, rstd,
+    # d_latent_mmd, sums3, loss, loss_scale, grad_scale, workspace, bytes, stream
+    "tvae_small_step_fwd": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _i64, _i64, _int,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _i64, _vp]),
+    # d_recon, d_reg, latent, pre, mean, rstd, gamma, Wd, We, h, stride_b, stride_s, d_latent_mmd, dh, dWe, dbe, dWd, dbd,
+    # dgamma, dbeta, B, S, n_eff, d, L, dtype, workspace, bytes, stream
+    "tvae_small_step_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp]),
 }
 
 _lock = threading.Lock()

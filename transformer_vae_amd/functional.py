@@ -192,6 +192,14 @@ def _mmd_code(dt: torch.dtype, strict_fp32: bool) -> int:
     return _DTYPES[dt]
 
 
+# the four-launch whole step of csrc/small_step.hip for the reference's own batch sizes (False: always the general path).
+# Measured crossover (graph-replayed step, MI355X): N = 40 latent rows (BASELINE cfg1) 74 us against 94 us on the general
+# kernels; N = 350 (cfg2) 140 us against 115 us -- one workgroup per row pair streams every weight through one CU, the
+# general path tiles the same products over the whole chip.  The C ABI takes up to 512 rows; the module uses it up to:
+SMALL_STEP = True
+SMALL_STEP_MAX_ROWS = 128
+
+
 class _MMDRegulariser(torch.autograd.Function):
     """reg = MMD(prior, latent) * scale, forward and gradient in one device pass
     (reference: autoencoders.py:117-136; closed-form gradient SURVEY.md 8a).
@@ -266,6 +274,34 @@ class _BottleneckStep(torch.autograd.Function):
         lib = _lib.lib()
         stream = _stream(hc)
         code = _DTYPES[dt]
+        has_lin, has_ln = Wd is not None, gamma is not None
+        want_grad = bool(grad_enabled) and any(ctx.needs_input_grad[:3])
+        ctx.small = False
+        if (SMALL_STEP and 0 < N <= SMALL_STEP_MAX_ROWS and dt == torch.float32 and has_lin and has_ln and prior.dtype == torch.float32
+                and lib.tvae_small_step_supported(B, n_eff, d, L) and hc.stride(0) % 4 == 0 and hc.stride(1) % 4 == 0
+                and hc.data_ptr() % 16 == 0):
+            # the reference's own batch sizes: the whole forward in two launches (csrc/small_step.hip)
+            Wdc, bdc, gc, btc = Wd.contiguous(), bd.contiguous(), gamma.contiguous(), beta.contiguous()
+            ya = prior.reshape(N, L).contiguous()
+            z = torch.empty((B, n_eff, L), dtype=dt, device=dev)
+            recon = torch.empty((N, d), dtype=dt, device=dev)
+            pre = torch.empty((N, d), dtype=dt, device=dev)
+            mean = torch.empty((N,), dtype=torch.float32, device=dev)
+            rstd = torch.empty((N,), dtype=torch.float32, device=dev)
+            sums = torch.empty(3, dtype=torch.float64, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            dz_mmd = torch.empty((N, L), dtype=dt, device=dev) if want_grad else None
+            loss_scale, grad_scale = mmd_scales(B, n_eff, N, L)
+            ws = _workspace(lib.tvae_small_step_fwd_workspace_bytes(B, n_eff, d, L), dev)
+            _lib.check(lib.tvae_small_step_fwd(_ptr(hc), hc.stride(0), hc.stride(1), _ptr(Wc), _ptr(bc), _ptr(Wdc), _ptr(bdc),
+                                               _ptr(gc), _ptr(btc), float(eps), _ptr(ya), B, n_eff, d, L, code, _ptr(z),
+                                               _ptr(recon), _ptr(pre), _ptr(mean), _ptr(rstd), _ptr(dz_mmd), _ptr(sums),
+                                               _ptr(loss), float(loss_scale), float(grad_scale), _ptr(ws), ws.numel(), stream),
+                       "tvae_small_step_fwd")
+            ctx.save_for_backward(hc, Wc, z, Wdc, gc, pre, mean, rstd, dz_mmd)
+            ctx.meta = (B, S, d, L, n_eff, dt)
+            ctx.small = True
+            return z, recon.view(B, n_eff, d), loss
         # --- encode (autoencoders.py:21-22)
         z = torch.empty((B, n_eff, L), dtype=dt, device=dev)
         ws = _workspace(lib.tvae_encode_fwd_workspace_bytes(B, n_eff, d, L), dev)
@@ -275,7 +311,6 @@ class _BottleneckStep(torch.autograd.Function):
         mdt = torch.bfloat16 if (dt == torch.bfloat16 and prior.dtype == torch.bfloat16) else torch.float32
         za = z.reshape(N, L).to(mdt)
         ya = prior.reshape(N, L).to(mdt).contiguous()
-        want_grad = bool(grad_enabled) and any(ctx.needs_input_grad[:3])
         loss_scale, grad_scale = mmd_scales(B, n_eff, N, L)
         mcode = _mmd_code(mdt, strict_fp32)
         ws_bytes = lib.tvae_mmd_workspace_bytes_for(N, N, L, int(want_grad), mcode)
@@ -289,7 +324,6 @@ class _BottleneckStep(torch.autograd.Function):
                                         float(loss_scale), _ptr(dz_mmd), float(grad_scale), _ptr(ws), ws.numel(),
                                         stream), "tvae_mmd_fwd_bwd")
         # --- decode (autoencoders.py:38-39, 66-67)
-        has_lin, has_ln = Wd is not None, gamma is not None
         Wdc = Wd.contiguous() if has_lin else None
         bdc = bd.contiguous() if has_lin else None
         gc = gamma.contiguous() if has_ln else None
@@ -320,6 +354,22 @@ class _BottleneckStep(torch.autograd.Function):
         has_lin, has_ln = Wdc is not None, gc is not None
         want_z = any(need[:3])
         dz = dWd = dbd = dgamma = dbeta = None
+        if (ctx.small and g_recon is not None and g_latent is None and g_recon.dtype == dt
+                and (g_reg is None or (dz_mmd is not None and g_reg.dtype == torch.float32 and g_reg.numel() == 1))):
+            # the usual training step at the reference's batch sizes: the whole backward in two launches
+            dc = g_recon.reshape(N, d).contiguous()
+            if dc.data_ptr() % 16 == 0:
+                mk = lambda shape, want: torch.empty(shape, dtype=dt, device=dev) if want else None
+                dh, dWe, dbe = mk((B, S, d), need[0]), mk((L, d), need[1]), mk((L,), need[2])
+                dWd, dbd, dgamma, dbeta = mk((d, L), need[3]), mk((d,), need[4]), mk((d,), need[5]), mk((d,), need[6])
+                use_reg = g_reg is not None and dz_mmd is not None
+                ws = _workspace(lib.tvae_small_step_bwd_workspace_bytes(B, n_eff, d, L), dev)
+                _lib.check(lib.tvae_small_step_bwd(_ptr(dc), _ptr(g_reg) if use_reg else None, _ptr(z), _ptr(pre), _ptr(mean),
+                                                   _ptr(rstd), _ptr(gc), _ptr(Wdc), _ptr(Wc), _ptr(hc), hc.stride(0),
+                                                   hc.stride(1), _ptr(dz_mmd) if use_reg else None, _ptr(dh), _ptr(dWe),
+                                                   _ptr(dbe), _ptr(dWd), _ptr(dbd), _ptr(dgamma), _ptr(dbeta), B, S, n_eff, d, L,
+                                                   code, _ptr(ws), ws.numel(), stream), "tvae_small_step_bwd")
+                return dh, dWe, dbe, dWd, dbd, dgamma, dbeta, None, None, None, None, None
         if g_recon is not None:
             dc = g_recon.to(dt).reshape(N, d).contiguous()
             dz = torch.empty((N, L), dtype=dt, device=dev) if want_z else None
