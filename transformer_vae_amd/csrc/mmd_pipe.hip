@@ -490,6 +490,9 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         }
     };
 
+    Src Xn2_c{};
+    int c_set_c = 0, c_p0_c = 0;
+    bool slow_c = true;
     // one interval; the buffer indices are compile-time constants (the loop below is unrolled by two)
     auto interval = [&](int k, auto cur_tag) {
 #ifdef TVAE_PIPE_UNROLL2
@@ -497,12 +500,13 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 #else
         const int cur = k & 1, nxt = cur ^ 1;
 #endif
-        int c_set, c_p0;
-        step_meta(sb + k, c_set, c_p0);
-        const Src Xn2 = step_src(sb + k + 2);
+        // this interval's scalars (c_set, c_p0, slow, Xn2) were worked out at the end of the previous one, behind its
+        // last matrix instructions, instead of at the top of this one with the matrix pipe idle
+        const Src Xn2 = Xn2_c;
+        const int c_set = c_set_c, c_p0 = c_p0_c;
         // Gram of the next tile  ||  E of this one (from tt, left by the previous interval)
         PHASE_MARK(5);
-        if (any_invalid || t_big || c_p0 + P > a.n_cols) front(std::true_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);   // wave-uniform
+        if (slow_c) front(std::true_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);   // wave-uniform
         else front(std::false_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);
         PHASE_MARK(0);
         grad_fetch_x(cur);          // in flight while the last matrix instructions of the Gram drain
@@ -522,6 +526,9 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         xch_reduce(nxt, nxt);
         PHASE_MARK(3);
         grad_run(cur, Xn2);
+        step_meta(sb + k + 1, c_set_c, c_p0_c);
+        Xn2_c = step_src(sb + k + 3);
+        slow_c = any_invalid || t_big || c_p0_c + P > a.n_cols;
         gram_prefetch(cur);         // the next interval's Gram runs on the tile just refilled into this buffer
         PHASE_MARK(4);
     };
@@ -543,6 +550,9 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
             asm volatile("" ::: "memory");
             xch_reduce(0, 0);
             gram_prefetch(1);
+            step_meta(sb, c_set_c, c_p0_c);
+            Xn2_c = step_src(sb + 2);
+            slow_c = any_invalid || t_big || c_p0_c + P > a.n_cols;
         }
 #ifdef TVAE_PIPE_UNROLL2
         for (int k = 0; k < nsteps; k += 2) {
