@@ -765,8 +765,26 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
     // instructions (norms of Xr into ring slot ring_r).  WITH_E: the tile whose partials sit in exchange buffer xbuf
     // (own partial in `own`, norms in ring slot ring_e, meta m) is finished between them.
     // DMA in flight on entry: the 1 + DPS KB instructions of the tile in the OTHER buffer; everything older has to land.
+    // (gram_prefetch: the k-step 0 operands of the next interval's Gram, read ahead of the barrier -- the tile is
+    // wave-private and has landed; measured neutral, 2.9 -> 3.1 ms at N = 32 768, kept for symmetry with the gradient kernel)
+    h16x8_t nab[PT], nal[SPLIT ? PT : 1];
+    auto gram_prefetch = [&](int b) {
+        const char* xs = sm + xbuf_byte(b);
+        wait_vmcnt_n(1 + DPS * KB);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            if constexpr (SPLIT) {
+                nab[pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off);
+                nal[pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 1024);
+            } else {
+                nab[pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 1024 * ((pt + my_pt) & (PT - 1)));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto front = [&](auto with_e_tag, int b, const Src& Xr, int ring_r, int xbuf, int ring_e, const Meta& m) {
         constexpr bool WITH_E = decltype(with_e_tag)::value;
+        constexpr bool PRE = WITH_E;                          // the loop's intervals: k-step 0 was read ahead
         const char* xs = sm + xbuf_byte(b);
         f32x4 part[TPW][3], cn;
         if constexpr (WITH_E) {
@@ -780,6 +798,11 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
         constexpr int GD = KB < TVAE_PIPE_GD ? KB : TVAE_PIPE_GD;
         h16x8_t ab[KB][PT], al[SPLIT ? KB : 1][PT];
         auto rd = [&](int sr) {
+            if (PRE && sr == 0) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) { ab[0][pt] = nab[pt]; if constexpr (SPLIT) al[0][pt] = nal[pt]; }
+                return;
+            }
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 if constexpr (SPLIT) {
@@ -821,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
             sum1 += (double)(m.set ? m.w * qs : 0.f);
         };
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        wait_vmcnt_n(1 + DPS * KB);
+        if (!PRE) wait_vmcnt_n(1 + DPS * KB);
 #pragma unroll
         for (int s = 0; s < GD; ++s) rd(s);
         stage_norms(Xr, ring_r);
@@ -859,16 +882,20 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
 #pragma unroll
             for (int s = 0; s < KB; ++s) dma_block(X1, 1, s);
             front(std::false_type{}, 0, X2, 2, 0, 0, Meta{0, 0, 1.f});
+            gram_prefetch(1);
             xch_write(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+        Meta m = step_meta(sb);
+        Src Xr = step_src(sb + 3);
         for (int k = 0; k < nsteps; ++k) {
             const int cur = k & 1, nxt = cur ^ 1;
-            const Meta m = step_meta(sb + k);
-            const Src Xr = step_src(sb + k + 3);
             front(std::true_type{}, nxt, Xr, (k + 3) & 3, cur, k & 3, m);
+            m = step_meta(sb + k + 1);                    // the next interval's scalars, ahead of the barrier wait
+            Xr = step_src(sb + k + 4);
+            gram_prefetch(cur);                           // interval k + 1 runs its Gram on buffer cur (tile k + 2)
             xch_write(nxt);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
