@@ -205,6 +205,11 @@ extern "C" int tvae_decode_fwd(const void* latent, const void* Wd, const void* b
         g.amap = dense_rows(L); g.bmap = dense_rows(L); g.cmap = dense_rows(d);
         g.epilogue = EPI_BIAS; g.dtype = dtype;
         g.slab = static_cast<float*>(workspace); g.slab_floats = workspace ? workspace_bytes / 4 : 0;
+        if (gamma) {        // large batches: linear + bias + LayerNorm by one launch (bit-identical to the two below)
+            bool fused = false;
+            TVAE_PROPAGATE(gemm_bias_layernorm(g, gamma, beta, eps, recon, mean, rstd, s, &fused));
+            if (fused) return TVAE_OK;
+        }
         TVAE_PROPAGATE(gemm_launch(g, s));
         ln_in = pre_norm;
     }

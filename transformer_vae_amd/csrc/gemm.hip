@@ -13,6 +13,8 @@
 //   read and how dh[:, :n] is scattered without a copy.
 //   Thin outputs with long K (the weight gradients: K = B*n rows) are split along K over
 //   blockIdx.z into fp32 slabs and summed in a fixed order (deterministic, no atomics).
+#include <cstdlib>
+
 #include "tvae_common.h"
 
 namespace tvae {
@@ -27,6 +29,9 @@ namespace {
 #endif
 #ifndef TVAE_PAIR_MAX
 #define TVAE_PAIR_MAX 4096
+#endif
+#ifndef TVAE_FUSED_LN_MIN_ROW_BLOCKS
+#define TVAE_FUSED_LN_MIN_ROW_BLOCKS 1024      // fused decode + LayerNorm from this many 64-row blocks on (4 per CU)
 #endif
 #ifdef TVAE_GEMM_MINWAVES
 #define TVAE_GEMM_BOUNDS __launch_bounds__(256, TVAE_GEMM_MINWAVES)
@@ -159,22 +164,98 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int n = n0 + wc * 32 + i32;
-    if (n >= a.N) return;
-    float bias = 0.f;
-    if (EPI != EPI_NONE && a.splits == 1) bias = to_f32(static_cast<const T*>(a.bias)[n]);
+    if (n < a.N) {          // (no early return: the row-block kernel below walks several tiles between barriers)
+        float bias = 0.f;
+        if (EPI != EPI_NONE && a.splits == 1) bias = to_f32(static_cast<const T*>(a.bias)[n]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= a.M) continue;
-        float v = acc[r];
-        if (a.splits > 1) {
-            a.slab[((long long)z * a.M + m) * a.N + n] = v;
-        } else {
-            if (EPI != EPI_NONE) v += bias;
-            if (EPI == EPI_BIAS_TANH) v = tanhf(v);
-            if (CSUM && csum && n == a.Nb) static_cast<T*>(a.csum)[m] = from_f32<T>(v);
-            else static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= a.M) continue;
+            float v = acc[r];
+            if (a.splits > 1) {
+                a.slab[((long long)z * a.M + m) * a.N + n] = v;
+            } else {
+                if (EPI != EPI_NONE) v += bias;
+                if (EPI == EPI_BIAS_TANH) v = tanhf(v);
+                if (CSUM && csum && n == a.Nb) static_cast<T*>(a.csum)[m] = from_f32<T>(v);
+                else static_cast<T*>(a.C)[a.cmap(m) + n] = from_f32<T>(v);
+            }
         }
+    }
+}
+
+// Decoder forward in ONE launch: pre = z Wd^T + bd for a block of 64 rows over ALL d columns, then LayerNorm of those
+// rows by the same workgroup while they are still in L2 (autoencoders.py:38-39 and :66-67 back to back).  Saves the
+// ln_fwd launch and its read of `pre` from HBM; `pre` is still written (the backward needs it).  The LayerNorm code
+// is ln_fwd_vec_kernel's (rowops.hip: one wave per row, same load pattern, same reductions), so the results are
+// bit-identical to the two-launch form.  d % 4 == 0, d <= 2048, K in one split.
+struct LnEpilogue { const void* gamma; const void* beta; void* out; float* mean; float* rstd; float eps; };
+
+__device__ __forceinline__ void store4_out(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4_out(bf16* p, const float v[4]) {
+    uint2 u;
+    u.x = (uint32_t)__bfloat16_as_ushort(__float2bfloat16(v[0])) | ((uint32_t)__bfloat16_as_ushort(__float2bfloat16(v[1])) << 16);
+    u.y = (uint32_t)__bfloat16_as_ushort(__float2bfloat16(v[2])) | ((uint32_t)__bfloat16_as_ushort(__float2bfloat16(v[3])) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+// (kept out of line: inlined into the column-tile loop the tile body grew from 76 to 184 VGPRs and lost the occupancy
+//  that hides its loads)
+template <typename T, int BKT>
+__device__ __noinline__ void gemm_tile_call(const GemmArgs& a, int bx, int by, float (*As)[LDS_LD], float (*Bs)[LDS_LD]) {
+    gemm_tile_body<T, false, false, EPI_BIAS, BKT>(a, bx, by, 0, As, Bs);
+}
+
+template <typename T, int BKT>
+__global__ TVAE_GEMM_BOUNDS void gemm_rows_ln_kernel(GemmArgs a, LnEpilogue e) {
+    __shared__ float As[BKT][LDS_LD];
+    __shared__ float Bs[BKT][LDS_LD];
+    const int nx = (a.N + BN - 1) / BN;
+#pragma unroll 1
+    for (int bx = 0; bx < nx; ++bx) gemm_tile_call<T, BKT>(a, bx, blockIdx.x, As, Bs);
+    __syncthreads();            // this workgroup's stores of `pre` are visible to all of its waves
+    // The row is read three times from L2 (sum, centred squares, output) instead of once into 32 registers: the GEMM
+    // part hides its loads through occupancy (76 VGPRs, six waves per SIMD); a register-resident row cost 184 and ran
+    // the whole launch 1.8x slower than the two-launch form.  Per-lane summation order = ln_fwd_vec_kernel's.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = a.N, ng = d >> 2;
+    const T* gamma = static_cast<const T*>(e.gamma);
+    const T* beta = static_cast<const T*>(e.beta);
+    for (int rr = wave; rr < BM; rr += 4) {
+        const long long row = (long long)blockIdx.x * BM + rr;
+        if (row >= a.M) break;
+        const T* x = static_cast<const T*>(a.C) + a.cmap((int)row);
+        float s = 0.f;
+#pragma unroll 1
+        for (int gidx = lane; gidx < ng; gidx += 64) {
+            float v[4];
+            load4_vec(x + 4 * gidx, v);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll 1
+        for (int gidx = lane; gidx < ng; gidx += 64) {
+            float v[4];
+            load4_vec(x + 4 * gidx, v);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = v[c] - mu; q = fmaf(t, t, q); }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)d + e.eps);
+        T* o = static_cast<T*>(e.out) + row * d;
+#pragma unroll 1
+        for (int gidx = lane; gidx < ng; gidx += 64) {
+            float v[4], gm[4], bt[4], w[4];
+            load4_vec(x + 4 * gidx, v);
+            load4_vec(gamma + 4 * gidx, gm);
+            load4_vec(beta + 4 * gidx, bt);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c] = (v[c] - mu) * rs * gm[c] + bt[c];
+            store4_out(o + 4 * gidx, w);
+        }
+        if (lane == 0) { e.mean[row] = mu; e.rstd[row] = rs; }
     }
 }
 
@@ -346,6 +427,36 @@ int gemm_launch(const GemmDesc& g, hipStream_t stream) {
     if (g.dtype == TVAE_F32) return launch_typed<float>(g, a, stream);
     if (g.dtype == TVAE_BF16) return launch_typed<bf16>(g, a, stream);
     return fail(TVAE_ERR_ARG, "gemm: unknown dtype %d", g.dtype);
+}
+
+// pre = A B^T + bias (row-major A (M, K), row-major B (N, K): the decoder's linear), then out = LayerNorm(pre) gamma + beta
+// with per-row mean / rstd, in one launch.  Returns TVAE_OK with *done = false when the shape is outside the fused
+// form (few row blocks: the two-launch form spreads the tiles over the chip; unaligned or wide rows; a K that wants
+// splitting) -- the caller then runs the two launches.
+int gemm_bias_layernorm(const GemmDesc& g, const void* gamma, const void* beta, float eps, void* out, float* mean,
+                        float* rstd, hipStream_t stream, bool* done) {
+    *done = false;
+    const int row_blocks = (g.M + BM - 1) / BM;
+    const bool aligned = aligned16(g.C) && aligned16(out) && aligned16(gamma) && aligned16(beta);
+    // Opt-in (environment TVAE_FUSED_DECODE_LN=1): measured at BASELINE cfg4 (3 840 row blocks, d = 1024, K = 768) the
+    // one launch takes 7.0 ms against 4.1 + 0.5 ms for the two -- a workgroup walks its sixteen column tiles one after
+    // the other and the out-of-line tile body runs at four waves per SIMD instead of six -- so the default stays two.
+    const char* opt = getenv("TVAE_FUSED_DECODE_LN");
+    if (!opt || opt[0] != '1') return TVAE_OK;
+    if (g.a_kmajor || g.b_kmajor || g.epilogue != EPI_BIAS || g.N % 4 != 0 || g.N > 2048 || !aligned ||
+        g.cmap.grp != 1 || g.cmap.so != g.N || row_blocks < TVAE_FUSED_LN_MIN_ROW_BLOCKS)
+        return TVAE_OK;
+    GemmArgs a;
+    TVAE_PROPAGATE(prepare_args(g, a));
+    // one split, 32-deep tiles: with >= 1024 row blocks occupancy hides the loads
+    a.splits = 1; a.k_per_split = (g.K + BK - 1) / BK * BK; a.deep = 0; a.slab = nullptr;
+    LnEpilogue e{gamma, beta, out, mean, rstd, eps};
+    if (g.dtype == TVAE_F32) hipLaunchKernelGGL((gemm_rows_ln_kernel<float, BK>), dim3(row_blocks), dim3(256), 0, stream, a, e);
+    else if (g.dtype == TVAE_BF16) hipLaunchKernelGGL((gemm_rows_ln_kernel<bf16, BK>), dim3(row_blocks), dim3(256), 0, stream, a, e);
+    else return fail(TVAE_ERR_ARG, "gemm: unknown dtype %d", g.dtype);
+    TVAE_CHECK_HIP(hipGetLastError());
+    *done = true;
+    return TVAE_OK;
 }
 
 namespace {

@@ -169,6 +169,9 @@ struct GemmDesc {
 };
 int64_t gemm_slab_floats(int M, int N, int K);
 int gemm_launch(const GemmDesc& g, hipStream_t stream);
+// linear + bias + LayerNorm in one launch when the shape allows (*done says whether it ran), gemm.hip
+int gemm_bias_layernorm(const GemmDesc& g, const void* gamma, const void* beta, float eps, void* out, float* mean,
+                        float* rstd, hipStream_t stream, bool* done);
 // activation-gradient + weight-gradient products of one projection; one launch when both are small
 // `zt` (nullable): a zero-fill that may ride in the same launch (its workgroups come first); *zt_done says whether it did
 int gemm_launch_pair(const GemmDesc& g_act, const GemmDesc& g_weight, hipStream_t stream,
