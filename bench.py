@@ -209,7 +209,7 @@ def side_config(cfg_name, device, graphed):
         clear()
         step(h, prior)
     torch.cuda.synchronize(device)
-    steps = 200 if cfg_name in ("cfg1", "cfg2") else 20
+    steps = 200 if cfg_name in ("cfg1", "cfg2") else 40
     if graphed:
         from transformer_vae_amd.graph import GraphedStep
         gs = GraphedStep(step, (h, prior), zero_grads=[h] + params)
@@ -299,7 +299,7 @@ def main():
     others = None
     if rank == 0 and world == 1 and not args.no_side_configs:
         others = []
-        for name, graphed in (("cfg1", False), ("cfg1", True), ("cfg2", False), ("cfg2", True), ("cfg3", False)):
+        for name, graphed in (("cfg1", False), ("cfg1", True), ("cfg2", False), ("cfg2", True), ("cfg3", False), ("cfg3", True)):
             if name == args.config:
                 continue
             try:
