@@ -70,8 +70,10 @@ class HipEvents:
 
 def mmd_mode(L, mmd_bf16, strict):
     """The arithmetic the MMD kernels of a (latent width, options) pair run in (transformer_vae_amd/csrc/mmd.hip, mmd_mode)."""
-    if L <= 192 or L > 1024:
+    if L > 1024:
         return "fp32"
+    if L <= 192:      # narrow latents: fp32 inputs take the split kernel of mmd_n16.hip, bf16 inputs are widened to fp32
+        return "fp32" if (strict or mmd_bf16) else "split"
     return "bf16" if mmd_bf16 else ("fp32" if strict else "split")
 
 
@@ -82,7 +84,8 @@ def mmd_roofline(mode, L, achieved, kern_ms, launches, traffic=None):
     if mode == "split":
         return {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None, "traffic": traffic,
-                "kernel": ("mmd_pipe_kernel<KB,true> + mmd_pipe_sum_kernel<KB,true>" if pipe else "mmd_bf16_kernel<KB,2,*,true>"),
+                "kernel": ("mmd_n16_kernel<KBN,RT,*>" if L <= 192 else
+                           "mmd_pipe_kernel<KB,true> + mmd_pipe_sum_kernel<KB,true>" if pipe else "mmd_bf16_kernel<KB,2,*,true>"),
                 "kernel_ms": kern_ms, "launches_timed": launches,
                 "products_per_fp32_product": 3, "executed_tflops": 3.0 * achieved if achieved else None,
                 "frac_executed": 3.0 * achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None,

@@ -168,7 +168,7 @@ int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all,
  * share that GPU's array: calls that overlap on one GPU (two streams, two host threads) race; serialise them.
  * The device of `stream` must be current.  The first call on a device looks the array's address up
  * (hipGetSymbolAddress): make it once outside graph capture. */
-#define TVAE_MMD_STATIC_SCRATCH_BYTES (32ll << 20)
+#define TVAE_MMD_STATIC_SCRATCH_BYTES (64ll << 20)
 int tvae_mmd_fwd_bwd_static(const void* z_all, const void* y_all,
                             int64_t n_total, int64_t row_offset, int64_t n_rows, int64_t D, int dtype,
                             double* sums3, float* loss, double loss_scale,

@@ -511,15 +511,18 @@ def test_mmd_is_bitwise_deterministic(N, D, dtype):
             assert torch.equal(loss.detach(), ref_loss) and torch.equal(zi.grad, ref_grad), it
 
 
-@pytest.mark.parametrize("N,D,dtype", [(8200, 77, torch.float32), (8290, 5, torch.float32), (9001, 33, torch.float32),
-                                       (8200, 64, torch.bfloat16)])
-def test_mmd_narrow_latents_64_row_kernel_vs_oracle(N, D, dtype):
-    """Large-N narrow latents take the 64-rows-per-wave kernel (mmd_narrow.hip): loss and gradient vs the fp64 oracle."""
+@pytest.mark.parametrize("N,D,dtype,strict", [(8200, 77, torch.float32, True), (8290, 5, torch.float32, True),
+                                              (9001, 33, torch.float32, True), (8200, 64, torch.bfloat16, False),
+                                              (8200, 77, torch.float32, False)])
+def test_mmd_narrow_latents_64_row_kernel_vs_oracle(N, D, dtype, strict):
+    """Large-N narrow latents on the fp32 kernels (strict fp32 or bf16 inputs) take the 64-rows-per-wave kernel
+    (mmd_narrow.hip); the last case is the same shape on the default split-fp16 kernel (mmd_n16.hip).  Loss and
+    gradient vs the fp64 oracle."""
     from transformer_vae_amd import functional as F
     rs = np.random.RandomState(N + D)
     zt = torch.from_numpy(np.tanh(rs.standard_normal((N, D))).astype(np.float32)).to(dev()).to(dtype).requires_grad_(True)
     yt = torch.from_numpy(rs.standard_normal((N, D)).astype(np.float32)).to(dev()).to(dtype)
-    reg = F.mmd_reg_loss(zt, yt, batch_size=1, n_latents=1)
+    reg = F.mmd_reg_loss(zt, yt, batch_size=1, n_latents=1, strict_fp32=strict)
     reg.backward()
     z64, y64 = zt.detach().double().cpu().numpy(), yt.double().cpu().numpy()
     ref = orc.mmd_gram(y64, z64)
@@ -551,6 +554,64 @@ def test_mmd_narrow_row_blocks_compose(R):
     assert torch.allclose(tot, sums_full, rtol=1e-7, atol=0)
     z64, y64 = z.double().cpu().numpy(), y.double().cpu().numpy()
     ref = orc.mmd_gram(y64, z64) * 192 / 64
+    assert abs(float(loss_full.detach()) - ref) <= F32_TOL * abs(ref)
+
+
+@pytest.mark.parametrize("N,D,spread", [(1024, 1, 1.0), (1100, 32, 1.0), (1500, 33, 1.0), (1300, 64, 1.0), (1111, 77, 1.0),
+                                        (1200, 100, 1.0), (1030, 128, 1.0), (1060, 129, 1.0), (1100, 160, 1.0),
+                                        (1024, 192, 1.0), (1111, 77, 9.0), (1300, 40, 30.0)])
+def test_mmd_narrow_split_fp16_kernel_vs_oracle(N, D, spread):
+    """fp32 latents up to 192 wide from 1 024 points on run as scaled fp16 pairs on the 16-bit matrix cores
+    (csrc/mmd_n16.hip, every feature-block count 1..6, ragged N): loss and gradient vs the fp64 oracle at the fp32
+    tolerance.  spread > 1 stretches the priors so that distances leave the polynomial range of expm1 (the exp form)."""
+    from transformer_vae_amd import functional as F, _lib
+    assert _lib.lib().tvae_mmd_workspace_bytes_for(N, N, D, 1, _lib.TVAE_F32) > 0
+    rs = np.random.RandomState(7 * N + D)
+    zt = torch.from_numpy(np.tanh(rs.standard_normal((N, D))).astype(np.float32)).to(dev()).requires_grad_(True)
+    yt = torch.from_numpy((spread * rs.standard_normal((N, D))).astype(np.float32)).to(dev())
+    reg = F.mmd_reg_loss(zt, yt, batch_size=1, n_latents=1)
+    reg.backward()
+    z64, y64 = zt.detach().double().cpu().numpy(), yt.double().cpu().numpy()
+    ref = orc.mmd_gram(y64, z64)
+    gref = orc.mmd_grad_latent_rows(z64, z64, y64)
+    assert abs(float(reg.detach()) - ref) <= F32_TOL * abs(ref), (float(reg.detach()), ref)
+    assert relerr(zt.grad.cpu().numpy(), gref) <= F32_TOL
+    # the strict fp32 kernels on the same inputs agree with it to the same tolerance
+    z2 = zt.detach().clone().requires_grad_(True)
+    reg2 = F.mmd_reg_loss(z2, yt, batch_size=1, n_latents=1, strict_fp32=True)
+    reg2.backward()
+    assert abs(float(reg2.detach()) - ref) <= F32_TOL * abs(ref)
+    assert relerr(z2.grad.cpu().numpy(), gref) <= F32_TOL
+    # forward only (no gradient launch) gives the same loss bits
+    with torch.no_grad():
+        reg3 = F.mmd_reg_loss(zt.detach(), yt, batch_size=1, n_latents=1)
+    assert abs(float(reg3) - float(reg.detach())) <= 1e-7 * abs(float(reg.detach()))
+
+
+@pytest.mark.parametrize("R,D", [(3, 77), (5, 77), (4, 48), (7, 150)])
+def test_mmd_narrow_split_row_blocks_compose(R, D):
+    """mmd_n16.hip row-sharded: blocks aligned to its 128- / 256-row workgroups (symmetric y-y walk) and ragged ones;
+    the shards' sums add up to the full call's and their gradients are its rows."""
+    from transformer_vae_amd import functional as F
+    N = 3072
+    gen = torch.Generator(device=dev()).manual_seed(R)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev()))
+    y = torch.randn((N, D), generator=gen, device=dev())
+    ls, gs = F.mmd_scales(64, 48, N, D)
+    zfull = z.clone().requires_grad_(True)
+    loss_full, sums_full = F.mmd_row_block(zfull, zfull, y, 0, ls, gs)
+    loss_full.backward()
+    tot = torch.zeros(3, dtype=torch.float64, device=dev())
+    bounds = [r * N // R for r in range(R + 1)]          # R = 3, 4: multiples of 256; R = 5, 7: not
+    for r in range(R):
+        rows = z[bounds[r]:bounds[r + 1]].clone().requires_grad_(True)
+        _, sums_r = F.mmd_row_block(rows, z, y, bounds[r], ls, gs)
+        _.backward()
+        tot += sums_r
+        assert relerr(rows.grad.cpu().numpy(), zfull.grad[bounds[r]:bounds[r + 1]].cpu().numpy()) <= 1e-6
+    assert torch.allclose(tot, sums_full, rtol=1e-7, atol=0)
+    z64, y64 = z.double().cpu().numpy(), y.double().cpu().numpy()
+    ref = orc.mmd_gram(y64, z64) * 48 / 64
     assert abs(float(loss_full.detach()) - ref) <= F32_TOL * abs(ref)
 
 

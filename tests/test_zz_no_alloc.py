@@ -79,14 +79,15 @@ def test_static_entry_rejects_oversize_and_bad_arguments():
     from transformer_vae_amd import _lib
     lib = _lib.lib()
     n, D = 32768, 768
-    assert lib.tvae_mmd_workspace_bytes_for(n, n, D, 1, _lib.TVAE_F32) > (32 << 20)
+    limit = 64 << 20                                             # TVAE_MMD_STATIC_SCRATCH_BYTES (include/tvae_hip.h)
+    assert lib.tvae_mmd_workspace_bytes_for(n, n, D, 1, _lib.TVAE_F32) > limit
     z = torch.zeros(16, dtype=torch.float32, device="cuda")     # never read: the size check comes first
     sums = torch.zeros(3, dtype=torch.float64, device="cuda")
     st = lib.tvae_mmd_fwd_bwd_static(z.data_ptr(), z.data_ptr(), n, 0, n, D, _lib.TVAE_F32, sums.data_ptr(), None, 1.0,
                                      z.data_ptr(), 1.0, None)
     assert st == 3, st                                           # TVAE_ERR_WORKSPACE
     msg = lib.tvae_last_error().decode()
-    assert "built-in buffer" in msg and str(32 << 20) in msg, msg
+    assert "built-in buffer" in msg and str(limit) in msg, msg
     st = lib.tvae_mmd_fwd_bwd_static(z.data_ptr(), z.data_ptr(), 0, 0, 0, 8, _lib.TVAE_F32, sums.data_ptr(), None, 1.0,
                                      None, 1.0, None)
     assert st == 1, st                                           # TVAE_ERR_ARG

@@ -793,6 +793,7 @@ struct Plan {
     int pipe_sum;     // 1 (with bf16_tiles): the sum-only launches run mmd_pipe_sum_kernel (64-row blocks too)
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
+    int n16;                // 1 (with split, without bf16_tiles): mmd_n16_kernel, narrow latents on the fp16 matrix cores
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
     int sp_major;     // 1: split-major workgroup order (see make_plan)
     int sync_epochs, sync_group, sync_groups;   // soft rendezvous of the gradient launch (sync_epochs == 0: off)
@@ -822,18 +823,32 @@ const Shape* pick_shape(int64_t D) {
 
 // Kernel family of a call.  Wide latents (192 < D <= 1024): bf16 inputs run on the bf16 matrix cores; fp32 inputs run
 // there too, as hi + lo bf16 pairs with three products per fp32 product (MODE_SPLIT, same 1e-5 accuracy class as the
-// fp32-input MFMA at 16x its rate), unless the caller asks for TVAE_F32_STRICT.  Narrow latents stay on the
-// single-wave fp32 kernels (bf16 inputs are widened exactly).
+// fp32-input MFMA at 16x its rate), unless the caller asks for TVAE_F32_STRICT.  Narrow latents (D <= 192): fp32
+// inputs run the same split arithmetic on the single-wave kernel of mmd_n16.hip; bf16 inputs and TVAE_F32_STRICT stay
+// on the single-wave fp32 kernels (bf16 inputs are widened exactly).
 enum { MODE_F32 = 0, MODE_BF16 = 1, MODE_SPLIT = 2 };
+#ifndef TVAE_N16
+#define TVAE_N16 1
+#endif
 int mmd_mode(int dtype, int64_t D) {
-    if (D <= 192 || D > 1024) return MODE_F32;
+    if (D > 1024) return MODE_F32;
+    if (D <= 192) return (TVAE_N16 && dtype == TVAE_F32) ? MODE_SPLIT : MODE_F32;
     return dtype == TVAE_BF16 ? MODE_BF16 : (dtype == TVAE_F32 ? MODE_SPLIT : MODE_F32);
 }
 
-bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int mode, Plan* p) {
+bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int mode, Plan* p) {  // mode by value: the narrow split mode may fall back
     const Shape* sh = pick_shape(D);
     if (!sh) return false;
-    const bool bf16_tiles = mode != MODE_F32;
+    // narrow split mode: padded to 32-feature blocks; the lo copy is reached through a 32-bit byte offset from the hi copy
+    p->n16 = 0;
+    if (mode == MODE_SPLIT && D <= 192) {
+        const int64_t dpad = align_up(D, 32);
+        // from 1 024 points on: below, the fp32 kernels finish in a few microseconds and the split mode's two extra
+        // launches (max |value|) cost more than its kernel saves (BASELINE cfg2, N = 350: 114 -> 119 us per step)
+        if (n_total >= 1024 && align_up(n_total, 256) * dpad < (1ll << 31) - (1ll << 20)) p->n16 = 1;
+        else mode = MODE_F32;
+    }
+    const bool bf16_tiles = mode != MODE_F32 && !p->n16;
     p->bf16_tiles = bf16_tiles ? 1 : 0;
     p->split = mode == MODE_SPLIT ? 1 : 0;
     p->NB = sh->nb;
@@ -844,10 +859,15 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
         p->NB = p->DPAD / 128;        // KB
         p->WAVES = 4;
     }
+    if (p->n16) {
+        p->DPAD = (int)align_up(D, 32);
+        p->NB = p->DPAD / 32;         // KBN
+        p->WAVES = 1;
+    }
     // Narrow latents: 64 rows per wave once the problem offers enough workgroups to fill the chip with them
     // (measured crossover at D = 77: N = 5 120 is 8 % faster on 32-row blocks, N = 8 192 is 35 % faster on 64).
     p->narrow64 = 0;
-    if (!bf16_tiles && p->WAVES == 1 && p->NB <= 5) {
+    if (!bf16_tiles && !p->n16 && p->WAVES == 1 && p->NB <= 5) {
         const int64_t tps64 = align_up(n_total, 64) / TILE_P;
         const int64_t cs64 = tps64 >= 32 ? (tps64 / 16 < 64 ? tps64 / 16 : 64) : 1;
         p->narrow64 = ((n_rows + 63) / 64) * cs64 >= 2048 ? 1 : 0;
@@ -860,16 +880,18 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     const bool pipe_ok = bf16_tiles && p->NB <= kPipeMaxKb && align_up(n_total, 64) * p->DPAD < (1ll << 31) - (1ll << 20);
     p->pipe = (pipe_ok && want_grad) ? 1 : 0;
     p->pipe_sum = (pipe_ok && (p->split || kPipeSumBf16)) ? 1 : 0;
-    const int rows_wg = (p->narrow64 || p->pipe_sum) ? 64 : ROWS_PER_WG;
+    const int rows_wg = p->n16 ? mmd_n16_rows(p->NB) : ((p->narrow64 || p->pipe_sum) ? 64 : ROWS_PER_WG);
     p->n_pad = (int)align_up(n_total, rows_wg);      // whole 32- (64-) point blocks (symmetric y-y enumeration)
     p->row_blocks = (int)((n_rows + rows_wg - 1) / rows_wg);
-    p->RT = (p->pipe || p->pipe_sum) ? 4 : 2;
+    p->RT = p->n16 ? rows_wg / 16 : ((p->pipe || p->pipe_sum) ? 4 : 2);
     p->row_blocks_g = p->narrow64 ? p->row_blocks : (int)((n_rows + 16 * p->RT - 1) / (16 * p->RT));
     p->n_rows_pad = p->narrow64 ? p->row_blocks * 64 : p->row_blocks_g * 16 * p->RT;
     p->tiles_per_set = p->n_pad / TILE_P;
     // Column splits: enough workgroups to fill the chip, and a count that fills the LAST round of
     // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
-    const int wg_per_cu = bf16_tiles ? ((!p->split && !p->pipe && !p->pipe_sum && p->NB <= 6) ? 2 : 1)
+    // (n16: four-wave workgroups, three per CU while a wave fits 168 registers, else two)
+    const int wg_per_cu = p->n16 ? ((p->NB == 1 || p->NB == 3) ? 3 : 2)
+                        : bf16_tiles ? ((!p->split && !p->pipe && !p->pipe_sum && p->NB <= 6) ? 2 : 1)
                                      : (p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1));
     const int slots = 256 * wg_per_cu;
     // at least 32 of the 2 * tiles_per_set column tiles per split (4 when the whole problem is tiny)
@@ -1155,7 +1177,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
 #ifdef TVAE_DEBUG_ENV
     if (getenv("TVAE_DEBUG_SP_MAJOR")) a.sp_major = atoi(getenv("TVAE_DEBUG_SP_MAJOR"));          // experiments only
 #endif
-    const int sym_rows = (p.narrow64 || p.pipe_sum) ? 64 : ROWS_PER_WG;      // row block of the symmetric y-y enumeration
+    const int sym_rows = p.n16 ? 16 * p.RT : ((p.narrow64 || p.pipe_sum) ? 64 : ROWS_PER_WG);      // row block of the symmetric y-y enumeration
     a.sym = (row_offset % sym_rows == 0 && (n_rows % sym_rows == 0 || row_offset + n_rows == n_total)) ? 1 : 0;
     a.wg_sums = reinterpret_cast<double*>(ws + p.off_sums);
     a.wg_rowsum = reinterpret_cast<double*>(ws + p.off_rowsum);
@@ -1168,7 +1190,11 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
-    if (d_z && !p.bf16_tiles && !p.narrow64 && p.WAVES == 1) {
+    if (p.n16) {
+        // narrow split mode: both problems in one launch, with or without the gradient
+        a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks;
+        TVAE_PROPAGATE(launch_mmd_n16(d_z != nullptr, p.NB, a, nwg0, nwg1, s));
+    } else if (d_z && !p.bf16_tiles && !p.narrow64 && p.WAVES == 1) {
         // single-wave shapes: both problems in one launch (row blocks are the same 32 rows in both)
         a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks;
         TVAE_PROPAGATE(launch_tile_both_shape(p.DPAD, a, nwg0, nwg1, s));

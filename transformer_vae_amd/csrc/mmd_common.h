@@ -146,5 +146,9 @@ int launch_mmd_bf16(bool grad, bool split, int kb, int rt, const MmdArgs& a, int
 int launch_mmd_pipe(bool grad, bool split, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 // fp32 kernel for narrow latents, 64 rows per single-wave workgroup (mmd_narrow.hip); nb = padded dimension / 16 (1..5)
 int launch_mmd_narrow(bool grad, int nb, const MmdArgs& a, int nblocks, hipStream_t s);
+// split-fp16 kernel for narrow latents, one wave per workgroup (mmd_n16.hip); kbn = padded dimension / 32 (1..6).
+// nwg0 workgroups of problem 0 (z rows, both column sets, gradient when grad), then nwg1 of problem 1 (y rows, priors)
+int mmd_n16_rows(int kbn);      // rows per workgroup
+int launch_mmd_n16(bool grad, int kbn, const MmdArgs& a, int nwg0, int nwg1, hipStream_t s);
 
 }  // namespace tvae
