@@ -36,8 +36,9 @@ extern "C" {
 #define TVAE_BF16 1
 /* tvae_mmd_* only: fp32 inputs with every product on the fp32-input matrix instruction (v_mfma_f32_16x16x4_f32).
  * Plain TVAE_F32 gives the MMD the same accuracy class (1e-5 of the fp32 reference on loss and gradient, fp32
- * accumulation, fp64 reductions) but, for 192 < latent_size <= 1024, forms each fp32 product from three bf16
- * matrix-core products of hi/lo halves (16 significant bits per operand), at several times the speed. */
+ * accumulation, fp64 reductions) but, for latent_size <= 1024 (latent_size <= 192: from 1024 points on), forms each
+ * fp32 product from three fp16 matrix-core products of scaled hi/lo halves (22 significant bits per operand), at
+ * several times the speed. */
 #define TVAE_F32_STRICT 2
 
 #define TVAE_OK 0
@@ -143,9 +144,9 @@ int tvae_decode_bwd(const void* d_recon, const void* latent, const void* Wd,
  *   d_z    (n_rows, D) out, nullable: grad_scale * sum-form gradient for the local rows,
  *          complete (needs no exchange):  pass grad_scale = 4 n / (B N^2 D^2) for
  *          d reg_loss / d latent  (SURVEY.md 8a).  Written in `dtype`.
- * Any D: fused tile kernels up to 1024 (D <= 192: fp32-input MFMA; wider: bf16 MFMA -- one product for
- * TVAE_BF16 inputs, three hi/lo products per fp32 product for TVAE_F32 inputs, fp32-input MFMA for
- * TVAE_F32_STRICT), strip-wise through the projection GEMM beyond.  n_total < 2^30. */
+ * Any D: fused tile kernels up to 1024 (TVAE_F32 inputs: three fp16 hi/lo products per fp32 product on the 16-bit
+ * matrix cores, D <= 192 from 1024 points on; TVAE_BF16 inputs wider than 192: one bf16 product; TVAE_F32_STRICT and
+ * everything else: fp32-input MFMA), strip-wise through the projection GEMM beyond.  n_total < 2^30. */
 int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad);
 /* Same, for the dtype the call will be made with (TVAE_F32 / TVAE_BF16).  tvae_mmd_workspace_bytes covers
  * either; bf16 calls with large column sets use one gradient slab per ~24 MB column chunk (up to 32 GiB in all),

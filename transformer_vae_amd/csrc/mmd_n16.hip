@@ -30,11 +30,13 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int N16_WAVES = 4;
+constexpr int N16_PT = 2;          // 16-point tiles per step (one barrier and one round of LDS-DMA per step)
 
 template <int KBN, int RT>
 struct N16Lds {
     static constexpr int TILE_B = KBN * 2048;                 // [s][hi | lo] pieces of 16 points x 32 features
-    static constexpr int NORM_OFF = 2 * TILE_B;               // [2][64] floats (16 used; the DMA moves 64)
+    static constexpr int STEP_B = N16_PT * TILE_B;            // [tile of the step][s][hi | lo]
+    static constexpr int NORM_OFF = 2 * STEP_B;               // [2][64] floats (16 N16_PT used; the DMA moves 64)
     static constexpr int E_OFF = NORM_OFF + 2 * 64 * 4;       // [wave][hi | lo][16 RT rows][16 points] fp16
     static constexpr int EPIECE_B = 16 * RT * 32;
     static constexpr int BYTES = E_OFF + N16_WAVES * 2 * EPIECE_B;
@@ -45,7 +47,7 @@ template <int KBN, int RT, bool GRAD>
 __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) void mmd_n16_kernel(MmdArgs a, int nwg0) {
     using L = N16Lds<KBN, RT>;
     constexpr int DPAD = 32 * KBN, ROWS = 16 * RT, RB = RT / 2;      // ROWS: per wave; RB: 32-row blocks of the gradient
-    constexpr int ROWS_WG = N16_WAVES * ROWS;
+    constexpr int ROWS_WG = N16_WAVES * ROWS, PT = N16_PT, STEP_P = PT * TILE_P;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
     const unsigned sm_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -106,9 +108,10 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
     }
 
     // column walk in 16-point tiles; symmetric y-y problem: unordered pairs of ROWS_WG-point blocks (parity rule of mmd.hip)
-    const long long tps = a.tiles_per_set;
+    // (walked in steps of PT tiles: ROWS_WG, the padding unit of the point sets, is a multiple of STEP_P)
+    const long long tps = a.tiles_per_set / PT;                 // steps per set
     const bool sym = problem == 1 && a.sym;
-    constexpr int BT = ROWS_WG / TILE_P;                        // tiles per block of the symmetric walk
+    constexpr int BT = ROWS_WG / STEP_P;                        // steps per block of the symmetric walk
     const int blkI = a.row_offset / ROWS_WG + rb;
     const int nJ = (int)(tps / BT);
     const int symA = (blkI + 1) >> 1;
@@ -148,26 +151,30 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
     auto locate = [&](int vt) -> TileRef {
         const int tile = actual(vt);
         const int set = tile >= tps ? 1 : 0;
-        return TileRef{set, (tile - (set ? (int)tps : 0)) * TILE_P};
+        return TileRef{set, (tile - (set ? (int)tps : 0)) * STEP_P};
     };
-    const int set_pts = (int)tps * TILE_P;
+    const int set_pts = (int)tps * STEP_P;
     auto step = [&](const TileRef& r, int vt_next) -> TileRef {       // the tile after r, vt_next its index in the walk
-        if (sym) return (vt_next % BT) ? TileRef{1, r.p0 + TILE_P} : locate(vt_next);
-        const bool wrap = r.p0 + TILE_P >= set_pts;                   // problem 0 only: latents, then priors
-        return TileRef{wrap ? 1 : r.set, wrap ? 0 : r.p0 + TILE_P};
+        if (sym) return (vt_next % BT) ? TileRef{1, r.p0 + STEP_P} : locate(vt_next);
+        const bool wrap = r.p0 + STEP_P >= set_pts;                   // problem 0 only: latents, then priors
+        return TileRef{wrap ? 1 : r.set, wrap ? 0 : r.p0 + STEP_P};
     };
-    // this wave's share of a tile -> buffer buf: the hi + lo pairs s = wave, wave + 4; the last wave also the norms
+    // this wave's share of a step -> buffer buf: the hi + lo pairs j = wave, wave + 4, .. of the step's PT KBN (pair j:
+    // tile j / KBN, feature block j % KBN); the last wave also the norms
     auto fetch = [&](const TileRef& r, int buf) {
         const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane(r.p0);
-        // all 64 lanes move a float (no lane mask, no branch): the words past the tile's 16 norms are never read, and
-        // the 48 floats past the end of a norm array are workspace of this call (mmd.hip, make_plan)
+        // all 64 lanes move a float (no lane mask, no branch): the words past the step's norms are never read, and
+        // the floats past the end of a norm array are workspace of this call (mmd.hip, make_plan)
         if (wave == N16_WAVES - 1)
             dma4((r.set ? nbase1 : nbase0) + p0, (unsigned)lane * 4u, sm_byte + (unsigned)(L::NORM_OFF + buf * 256));
         const float* X = reinterpret_cast<const float*>((r.set ? cbase1 : cbase0) + p0 * (unsigned)DPAD);   // the plan keeps n_pad * DPAD < 2^31
 #pragma unroll
-        for (int s0 = 0; s0 < KBN; s0 += N16_WAVES) {
-            const int s = s0 + wave;
-            if (s < KBN) dma16_pair(X + 16 * s, dma_voff, dma_voff_lo, sm_byte + (unsigned)(buf * L::TILE_B + 2048 * s));
+        for (int j0 = 0; j0 < PT * KBN; j0 += N16_WAVES) {
+            const int j = j0 + wave;
+            if (j < PT * KBN) {
+                const int u = j / KBN, s = j - u * KBN;
+                dma16_pair(X + (u * TILE_P * DPAD + 32 * s) / 2, dma_voff, dma_voff_lo, sm_byte + (unsigned)(buf * L::STEP_B + 2048 * j));
+            }
         }
     };
 
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
     constexpr float X_EXP = -EM1_POLY_MAX * SPLIT_E_SCALE;      // at or below: library exp
     constexpr float UNSCALE = 1.f / SPLIT_E_SCALE;
 
-    // fp32 partials (scaled, two slots per lane), flushed to fp64 every 8 tiles and when the column set changes
+    // fp32 partials (scaled, two slots per lane), flushed to fp64 every 8 steps and when the column set changes
     double sum0 = 0.0, sum1 = 0.0, rowsum[RT];
     f32x2 qacc = {0.f, 0.f}, facc[RT];
     int qset = 0;
@@ -206,20 +213,23 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
 #endif
     TileRef cur = locate(tb < te ? tb : 0), nxt = cur;
     if (tb < te) fetch(cur, 0);
-    for (int tile = tb; tile < te; ++tile) {
+    for (int tile = tb; tile < te; ++tile) {                // (`tile`: a step of PT tiles)
         PHASE_MARK(5);
         cur = nxt;
-        const int set = cur.set, p0 = cur.p0;
-        const float wsym = (sym && p0 / ROWS_WG != blkI) ? 2.f : 1.f;
+        const int set = __builtin_amdgcn_readfirstlane(cur.set), p0s = __builtin_amdgcn_readfirstlane(cur.p0);
+        const float wsym = (sym && p0s / ROWS_WG != blkI) ? 2.f : 1.f;
         const float sgn = set ? -1.f : 1.f;                 // prior columns enter the gradient and the row sums with s_p = -1
         const int buf = (tile - tb) & 1;
-        const char* xs = sm + buf * L::TILE_B;
         if (set != qset) { flush(); qset = set; }
-        wait_vmcnt<0>();                                    // this wave's share of tile `tile` has landed ...
+        wait_vmcnt<0>();                                    // this wave's share of the step has landed ...
         __syncthreads();                                    // ... everyone's has, and the other buffer is free again
         PHASE_MARK(0);
         if (tile + 1 < te) { nxt = step(cur, tile + 1); fetch(nxt, buf ^ 1); }
         PHASE_MARK(1);
+#pragma unroll 1       // (unrolled, the two tiles' live ranges overlap: 28-68 B of scratch per lane)
+      for (int u = 0; u < PT; ++u) {
+        const int p0 = p0s + u * TILE_P;
+        const char* xs = sm + buf * L::STEP_B + u * L::TILE_B;
 
         // 1. Gram: S[t][r] = <x_p, z_i> (scaled), p = p0 + 4 g + r, i = i0 + 16 t + i16
         f32x4 S[RT];
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
         // 2. E = expm1(-t), two values per instruction (v_pk_*_f32); h = 0: points 4 g, 4 g + 1; h = 1: + 2, + 3.
         // One row tile at a time, through to its E pieces in LDS (short live ranges: the register budget of two or
         // three waves per SIMD is what this kernel lives on).
-        const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + buf * 256 + 16 * g);
+        const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + buf * 256 + u * 64 + 16 * g);
         const f32x2 cn2[2] = {f32x2{cn[0], cn[1]} * nscale, f32x2{cn[2], cn[3]} * nscale};
         const bool ragged = p0 + TILE_P > a.n_cols;
         char* eb = sm + L::E_OFF + wave * (2 * L::EPIECE_B);
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
                 Bh[b] = *reinterpret_cast<const f16x8_t*>(eb + at);
                 Bl[b] = *reinterpret_cast<const f16x8_t*>(eb + L::EPIECE_B + at);
             }
-            const int xb0 = buf * L::TILE_B;
+            const int xb0 = buf * L::STEP_B + u * L::TILE_B;
 #pragma unroll
             for (int s = 0; s < KBN; ++s) {
                 const s16x4_t h0 = tr_read(xb0 + 2048 * s + tr_off[0]), h1 = tr_read(xb0 + 2048 * s + tr_off[1]);
@@ -329,8 +339,9 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
                 for (int b = 0; b < RB; ++b) acc[s][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[b], acc[s][b], 0, 0, 0);
             }
         }
-        if (((tile - tb) & 7) == 7) flush();
         PHASE_MARK(4);
+      }
+        if (((tile - tb) & 7) == 7) flush();
     }
     flush();
     wait_vmcnt<0>();
