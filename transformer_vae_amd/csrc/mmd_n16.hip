@@ -43,7 +43,9 @@ struct N16Lds {
     static_assert(N16_WAVES * 2 * EPIECE_B >= (2 * N16_WAVES) * 8, "final reduction reuses the E buffers");
 };
 
-template <int KBN, int RT, bool GRAD>
+// EDGE = false: the launch has no partial row block and no partial point step (picked on the host), so the
+// invalid-row and ragged-tile selects are not even compiled in
+template <int KBN, int RT, bool GRAD, bool EDGE>
 __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) void mmd_n16_kernel(MmdArgs a, int nwg0) {
     using L = N16Lds<KBN, RT>;
     constexpr int DPAD = 32 * KBN, ROWS = 16 * RT, RB = RT / 2;      // ROWS: per wave; RB: 32-row blocks of the gradient
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
         for (int s = 0; s < KBN; ++s) { asm volatile("" : "+v"(zreg[t][s])); asm volatile("" : "+v"(zlo[t][s])); }
         asm volatile("" : "+v"(rn[t]));
     }
-    const bool any_invalid = __any(!all_valid);
+    const bool any_invalid = EDGE && __any(!all_valid);
 
     f32x16 acc[GRAD ? KBN : 1][GRAD ? RB : 1];
     if (GRAD) {
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
         // three waves per SIMD is what this kernel lives on).
         const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + buf * 256 + u * 64 + 16 * g);
         const f32x2 cn2[2] = {f32x2{cn[0], cn[1]} * nscale, f32x2{cn[2], cn[3]} * nscale};
-        const bool ragged = p0 + TILE_P > a.n_cols;
+        const bool ragged = EDGE && p0 + TILE_P > a.n_cols;
         char* eb = sm + L::E_OFF + wave * (2 * L::EPIECE_B);
         f32x2 qt = {0.f, 0.f};
 #pragma unroll
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
                         qs[h][c] = big ? ex - Xv : qs[h][c];
                     }
             }
-            if (any_invalid && !valid_i[t]) { es[0] = es[1] = f32x2{0.f, 0.f}; qs[0] = qs[1] = f32x2{0.f, 0.f}; }
-            if (ragged) {
+            if (EDGE && any_invalid && !valid_i[t]) { es[0] = es[1] = f32x2{0.f, 0.f}; qs[0] = qs[1] = f32x2{0.f, 0.f}; }
+            if (EDGE && ragged) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -383,11 +385,17 @@ __global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) voi
     }
 }
 
+template <int KBN, int RT, bool GRAD, bool EDGE>
+void launch_n16_inst(const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
+    constexpr int lds_bytes = N16Lds<KBN, RT>::BYTES;
+    hipLaunchKernelGGL((mmd_n16_kernel<KBN, RT, GRAD, EDGE>), dim3(nwg0 + nwg1), dim3(64 * N16_WAVES), lds_bytes, s, a, nwg0);
+}
+
 template <int KBN, int RT>
 int launch_n16(bool grad, const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
-    constexpr int lds_bytes = N16Lds<KBN, RT>::BYTES;
-    if (grad) hipLaunchKernelGGL((mmd_n16_kernel<KBN, RT, true>), dim3(nwg0 + nwg1), dim3(64 * N16_WAVES), lds_bytes, s, a, nwg0);
-    else hipLaunchKernelGGL((mmd_n16_kernel<KBN, RT, false>), dim3(nwg0 + nwg1), dim3(64 * N16_WAVES), lds_bytes, s, a, nwg0);
+    const bool edge = a.n_rows % (N16_WAVES * 16 * RT) != 0 || a.n_cols % (N16_PT * TILE_P) != 0;
+    if (grad) { if (edge) launch_n16_inst<KBN, RT, true, true>(a, nwg0, nwg1, s); else launch_n16_inst<KBN, RT, true, false>(a, nwg0, nwg1, s); }
+    else { if (edge) launch_n16_inst<KBN, RT, false, true>(a, nwg0, nwg1, s); else launch_n16_inst<KBN, RT, false, false>(a, nwg0, nwg1, s); }
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }
