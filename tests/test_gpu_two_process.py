@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 CASES = {
     # name: (B_global, S, d, n, L)
     "narrow_D77": (64, 12, 96, 5, 77),
+    "narrow_D77_split": (300, 6, 64, 5, 77),      # N = 1 500: the split-fp16 kernel for narrow latents, ragged row blocks
     "wide_D768_split": (96, 8, 128, 8, 768),
     "wide_D300_ragged": (50, 6, 64, 5, 300),
 }

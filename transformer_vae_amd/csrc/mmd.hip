@@ -802,7 +802,7 @@ struct Plan {
 
 // (padded dimension, waves per workgroup, 16-column blocks per wave); DPAD = WAVES * 16 * NB
 struct Shape { int dpad, waves, nb; };
-// Narrow latents (<= 192): one wave per workgroup owns all features of its 32 rows (no exchange, no
+// Narrow latents (<= 192) on the fp32 kernels: one wave per workgroup owns all features of its 32 rows (no exchange, no
 // barrier); wider ones slice the features over 4 (8) waves.
 const Shape kShapes[] = {{16, 1, 1}, {32, 1, 2}, {48, 1, 3}, {64, 1, 4}, {80, 1, 5}, {96, 1, 6}, {112, 1, 7},
                          {128, 1, 8}, {160, 1, 10}, {192, 1, 12}, {256, 4, 4}, {384, 4, 6},
