@@ -198,11 +198,17 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         p0 = (u - (set ? nS : 0)) * P;
 #endif
     };
+    // both sets' bases in scalar registers, picked by a scalar select (indexing a.cols[set] is a scalar memory load
+    // per step, and hipcc then did the pointer arithmetic in vector registers: ~25 instructions per step)
+    const bf16* const cbase0 = reinterpret_cast<const bf16*>(a.cols[0]) + wave * SW;
+    const bf16* const cbase1 = reinterpret_cast<const bf16*>(a.cols[1]) + wave * SW;
+    const float* const nbase0 = a.cnorm[0];
+    const float* const nbase1 = a.cnorm[1];
     auto step_src = [&](int v) -> Src {
         int set, p0;
         step_meta(v, set, p0);
-        const unsigned off = (unsigned)p0 * (unsigned)DPAD + (unsigned)(wave * SW);      // the plan keeps n_pad * DPAD < 2^31
-        return Src{reinterpret_cast<const bf16*>(a.cols[set]) + off, a.cnorm[set] + p0, set, p0};
+        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(p0) * (unsigned)DPAD;   // the plan keeps n_pad * DPAD < 2^31
+        return Src{(set ? cbase1 : cbase0) + off, (set ? nbase1 : nbase0) + p0, set, p0};
     };
     auto xbuf_byte = [&](int b) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
     auto stage_norms = [&](const Src& X, int nbuf) {
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 //
 // and a feature block of the tile under the Gram is refilled right behind its matrix instructions with tile k + 3
 // (two tile buffers: k + 1 under the Gram, k + 2 landed or landing).  Point norms sit in a ring of four.
-// The exp form and the ragged-edge masks are always compiled in (there is vector time to spare without a gradient).
+// The exp form and the ragged-edge masks sit in a fix-up behind a wave-uniform test at the end of a step's E work.
 // ------------------------------------------------------------------------------------------------------------------
 template <int KB, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
@@ -672,10 +678,12 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
     const float gram_unscale2 = SPLIT ? 2.f * split_scales(*a.split_amax).inv_s2 : 2.f;
     bool my_valid[TPW];
     float rn[TPW];
+    bool all_valid_s = true;
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         const int my_row = i0 + 16 * (my_t0 + j) + i16;
         my_valid[j] = my_row < a.n_rows;
+        all_valid_s = all_valid_s && my_valid[j];
         rn[j] = my_valid[j] ? rnorm[my_row] : 0.f;
     }
 #pragma unroll
@@ -687,6 +695,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
         }
 #pragma unroll
     for (int j = 0; j < TPW; ++j) asm volatile("" : "+v"(rn[j]));
+    const bool any_invalid = __any(!all_valid_s);
 
     // steps of P points.  Problem 0 (z rows): both column sets.  Problem 1 (y rows): the priors -- all of them, or (sym)
     // each unordered pair of 64-point blocks once, pairs other than the diagonal weighted 2: row block I takes the
@@ -733,10 +742,14 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
     auto xbuf_byte = [&](int b) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
     // all DMA of one step: its norms into ring slot `ring`; its feature blocks one by one (dma_block)
     struct Src { const bf16* x; const float* nrm; };
+    const bf16* const cbase0 = reinterpret_cast<const bf16*>(a.cols[0]) + wave * SW;      // scalar bases: see mmd_pipe_kernel
+    const bf16* const cbase1 = reinterpret_cast<const bf16*>(a.cols[1]) + wave * SW;
+    const float* const nbase0 = a.cnorm[0];
+    const float* const nbase1 = a.cnorm[1];
     auto step_src = [&](int v) -> Src {
         const Meta m = step_meta(v);
-        const unsigned off = (unsigned)m.p0 * (unsigned)DPAD + (unsigned)(wave * SW);
-        return Src{reinterpret_cast<const bf16*>(a.cols[m.set]) + off, a.cnorm[m.set] + m.p0};
+        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(m.p0) * (unsigned)DPAD;
+        return Src{(m.set ? cbase1 : cbase0) + off, (m.set ? nbase1 : nbase0) + m.p0};
     };
     auto stage_norms = [&](const Src& X, int ring) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(NORM4_OFF + (ring * 4 + wave) * 64 * 4));
@@ -826,17 +839,28 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
                     for (int r = 0; r < 4; ++r) tt[4 * j + r] = fmaxf((cn[r] + rn[j] - gram_unscale2 * sv[r]) * a.inv_d2, 0.f);
                 }
             }
+            // the polynomial alone between the matrix instructions (every instruction issued here adds to the step:
+            // DESIGN 4.1f); the exp form for t >= 1/8 and the masks of ragged edges in a fix-up behind a wave-uniform
+            // test at the end, which almost no step takes
 #pragma unroll
             for (int el = 0; el < NE; ++el) {
                 if (el * (FIN + 1) / NE != s) continue;
-                const int j = el >> 2, r = el & 3;
-                const EQ pl = em1_split(tt[el]);
-                const float ex = __expf(-tt[el]) - 1.f;
-                const bool big = tt[el] >= EM1_POLY_MAX;
-                const bool ok = my_valid[j] && (m.p0 + 16 * my_pt + 4 * g + r < a.n_cols);
-                q[el] = ok ? (big ? ex + tt[el] : pl.q) : 0.f;
+                q[el] = em1_split(tt[el]).q;
             }
             if (s != FIN) return;
+            float tm = tt[0];
+#pragma unroll
+            for (int el = 1; el < NE; ++el) tm = fmaxf(tm, tt[el]);
+            if (any_invalid || m.p0 + P > a.n_cols || __any(tm >= EM1_POLY_MAX)) {
+#pragma unroll
+                for (int el = 0; el < NE; ++el) {
+                    const int j = el >> 2, r = el & 3;
+                    const float ex = __expf(-tt[el]) - 1.f;
+                    const bool big = tt[el] >= EM1_POLY_MAX;
+                    const bool ok = my_valid[j] && (m.p0 + 16 * my_pt + 4 * g + r < a.n_cols);
+                    q[el] = ok ? (big ? ex + tt[el] : q[el]) : 0.f;
+                }
+            }
             float qs = 0.f;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) qs += (q[4 * j] + q[4 * j + 1]) + (q[4 * j + 2] + q[4 * j + 3]);
