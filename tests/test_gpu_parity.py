@@ -793,7 +793,8 @@ def test_mmd_tiny_sample_counts(N, D):
 @pytest.mark.parametrize("N,D,scale,dtype", [(300, 5, 8.0, torch.float32), (700, 77, 12.0, torch.float32),
                                              (9000, 40, 6.0, torch.float32), (600, 768, 30.0, torch.float32),
                                              (600, 768, 30.0, torch.bfloat16), (200, 1100, 40.0, torch.float32),
-                                             (256, 64, 0.0, torch.float32)])
+                                             (256, 64, 0.0, torch.float32), (1280, 77, 0.0, torch.float32),
+                                             (1100, 40, 25.0, torch.float32), (640, 512, 0.0, torch.float32)])
 def test_mmd_far_apart_and_coincident_points(N, D, scale, dtype):
     """Large distances (t beyond the polynomial range: the library-exp branch of every kernel family, E -> -1) and,
     with scale 0, priors that coincide with the latents (t = 0 exactly, clamped)."""
@@ -814,6 +815,19 @@ def test_mmd_far_apart_and_coincident_points(N, D, scale, dtype):
     else:
         assert abs(float(reg.detach())) <= 1e-9 and abs(ref) <= 1e-12       # MMD of a sample with itself is 0
         assert float(zt.grad.abs().max()) <= 1e-6 * max(np.abs(gref).max(), 1e-12) + 1e-12
+
+
+@pytest.mark.parametrize("N,D", [(1024, 77), (512, 768), (300, 33)])
+def test_mmd_all_zero_inputs(N, D):
+    """Latents and priors all zero (the split modes' max |value| is 0: the scale falls back to 2^12): every kernel
+    value is exp(0) = 1, the MMD is exactly 0 and so is its gradient."""
+    from transformer_vae_amd import functional as F
+    zt = torch.zeros((N, D), device=dev(), requires_grad=True)
+    yt = torch.zeros((N, D), device=dev())
+    reg = F.mmd_reg_loss(zt, yt, batch_size=1, n_latents=1)
+    reg.backward()
+    assert float(reg.detach()) == 0.0
+    assert bool(torch.isfinite(zt.grad).all()) and float(zt.grad.abs().max()) == 0.0
 
 
 def _random_step_shapes(count, seed):
