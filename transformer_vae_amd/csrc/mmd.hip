@@ -889,8 +889,8 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     p->tiles_per_set = p->n_pad / TILE_P;
     // Column splits: enough workgroups to fill the chip, and a count that fills the LAST round of
     // resident workgroups too (a 1.9-round launch wastes 7 % of the machine on its half-empty tail).
-    // (n16: four-wave workgroups, three per CU while a wave fits 168 registers, else two)
-    const int wg_per_cu = p->n16 ? ((p->NB == 1 || p->NB == 3) ? 3 : 2)
+    // (n16: four-wave workgroups, as many per CU as its waves' registers allow per SIMD)
+    const int wg_per_cu = p->n16 ? mmd_n16_wg_per_cu(p->NB)
                         : bf16_tiles ? ((!p->split && !p->pipe && !p->pipe_sum && p->NB <= 6) ? 2 : 1)
                                      : (p->WAVES == 1 ? 8 : (p->WAVES == 4 && p->NB <= 12 ? 2 : 1));
     const int slots = 256 * wg_per_cu;

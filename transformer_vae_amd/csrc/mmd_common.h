@@ -149,6 +149,7 @@ int launch_mmd_narrow(bool grad, int nb, const MmdArgs& a, int nblocks, hipStrea
 // split-fp16 kernel for narrow latents, one wave per workgroup (mmd_n16.hip); kbn = padded dimension / 32 (1..6).
 // nwg0 workgroups of problem 0 (z rows, both column sets, gradient when grad), then nwg1 of problem 1 (y rows, priors)
 int mmd_n16_rows(int kbn);      // rows per workgroup
+int mmd_n16_wg_per_cu(int kbn); // resident workgroups per CU (registers)
 int launch_mmd_n16(bool grad, int kbn, const MmdArgs& a, int nwg0, int nwg1, hipStream_t s);
 
 }  // namespace tvae

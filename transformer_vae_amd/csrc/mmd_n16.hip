@@ -3,9 +3,9 @@
 // shapes the reference actually ships (latent_size 77).
 //
 // Each of the four waves of a workgroup owns 16 RT rows with ALL features in registers (no exchange of partial
-// products); DPAD = 32 KBN features.  RT = 4 (64 rows per wave) up to 64 features, RT = 2 (32 rows) up to 192: rows
-// and accumulators have to leave room for two or three waves per SIMD, which is what overlaps one wave's expm1 work
-// with the others' matrix instructions.  The four waves SHARE the column tiles: one LDS-DMA of a tile serves 64 RT
+// products); DPAD = 32 KBN features.  RT = 2 (32 rows per wave): rows and accumulators have to leave room for two to
+// four waves per SIMD, which is what covers one wave's waits (LDS round trip of E, matrix results) with the others'
+// instructions.  The four waves SHARE the column tiles: one LDS-DMA of a tile serves 64 RT
 // rows, and one barrier per tile hands the double buffer over.  (A first version with one wave per workgroup, every
 // wave streaming its own tiles, ran at the pace of the L2 -> LDS path: 124 us at N = 5 120, D = 77, about 30 GB/s
 // per CU, the guide's Infinity-Cache gather rate.)
@@ -30,7 +30,11 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int N16_WAVES = 4;
-constexpr int N16_PT = 2;          // 16-point tiles per step (one barrier and one round of LDS-DMA per step)
+constexpr int N16_PT = 2;
+#ifndef TVAE_N16_RT_SMALL
+#define TVAE_N16_RT_SMALL 2        // row tiles per wave for KBN <= 2 (4: measured 6 % slower at N = 8 192, D = 64 and 30 % at N = 2 048, D = 32)
+#endif
+constexpr int N16_WPE(int kbn, int rt) { return rt == 2 ? (kbn == 1 ? 4 : (kbn <= 3 ? 3 : 2)) : (kbn == 1 ? 3 : 2); }   // waves per SIMD asked of hipcc          // 16-point tiles per step (one barrier and one round of LDS-DMA per step)
 
 template <int KBN, int RT>
 struct N16Lds {
@@ -46,7 +50,7 @@ struct N16Lds {
 // EDGE = false: the launch has no partial row block and no partial point step (picked on the host), so the
 // invalid-row and ragged-tile selects are not even compiled in
 template <int KBN, int RT, bool GRAD, bool EDGE>
-__global__ __launch_bounds__(64 * N16_WAVES, (KBN == 1 || KBN == 3) ? 3 : 2) void mmd_n16_kernel(MmdArgs a, int nwg0) {
+__global__ __launch_bounds__(64 * N16_WAVES, N16_WPE(KBN, RT)) void mmd_n16_kernel(MmdArgs a, int nwg0) {
     using L = N16Lds<KBN, RT>;
     constexpr int DPAD = 32 * KBN, ROWS = 16 * RT, RB = RT / 2;      // ROWS: per wave; RB: 32-row blocks of the gradient
     constexpr int ROWS_WG = N16_WAVES * ROWS, PT = N16_PT, STEP_P = PT * TILE_P;
@@ -402,12 +406,13 @@ int launch_n16(bool grad, const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
 
 }  // namespace
 
-int mmd_n16_rows(int kbn) { return N16_WAVES * (kbn <= 2 ? 64 : 32); }
+int mmd_n16_rows(int kbn) { return N16_WAVES * 16 * (kbn <= 2 ? TVAE_N16_RT_SMALL : 2); }
+int mmd_n16_wg_per_cu(int kbn) { return N16_WPE(kbn, kbn <= 2 ? TVAE_N16_RT_SMALL : 2); }      // four-wave workgroups: one wave per SIMD each
 
 int launch_mmd_n16(bool grad, int kbn, const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
     switch (kbn) {
-        case 1: return launch_n16<1, 4>(grad, a, nwg0, nwg1, s);
-        case 2: return launch_n16<2, 4>(grad, a, nwg0, nwg1, s);
+        case 1: return launch_n16<1, TVAE_N16_RT_SMALL>(grad, a, nwg0, nwg1, s);
+        case 2: return launch_n16<2, TVAE_N16_RT_SMALL>(grad, a, nwg0, nwg1, s);
         case 3: return launch_n16<3, 2>(grad, a, nwg0, nwg1, s);
         case 4: return launch_n16<4, 2>(grad, a, nwg0, nwg1, s);
         case 5: return launch_n16<5, 2>(grad, a, nwg0, nwg1, s);
