@@ -23,7 +23,7 @@ rows = int(sys.argv[5]) if len(sys.argv) > 5 else N
 CODES = {"split": 0, "bf16": 1, "strict": 2}
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
-z = torch.tanh(torch.randn((N, D), generator=g, device=dev))
+z = torch.tanh(torch.randn((N, D), generator=g, device=dev) + float(os.environ.get("TVAE_MODES_SHIFT", "0")))   # shift: latents with a non-zero mean
 y = torch.randn((N, D), generator=g, device=dev)
 lib = _lib.lib()
 ls, gs = 1.0 / float(N) ** 2, 4.0 / (float(N) ** 2 * float(D) ** 2)

@@ -288,8 +288,10 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
                 if constexpr (SPLIT) {
                     S[0][t] = mfma16<SPLIT>(ab[s][0], zlo[t][s], S[0][t]);
                     S[1][t] = mfma16<SPLIT>(ab[s][1], zlo[t][s], S[1][t]);
+#if TVAE_GRAM_PRODUCTS == 3
                     S[0][t] = mfma16<SPLIT>(al[s][0], zreg[t][s], S[0][t]);
                     S[1][t] = mfma16<SPLIT>(al[s][1], zreg[t][s], S[1][t]);
+#endif
                 }
             }
             if (!GRAD) {

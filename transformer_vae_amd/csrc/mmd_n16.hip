@@ -9,7 +9,7 @@
 // rows, and one barrier per tile hands the double buffer over.  (A first version with one wave per workgroup, every
 // wave streaming its own tiles, ran at the pace of the L2 -> LDS path: 124 us at N = 5 120, D = 77, about 30 GB/s
 // per CU, the guide's Infinity-Cache gather rate.)
-//   Gram      S'[p][i] over 32-feature k-steps, v_mfma_f32_16x16x32_f16:   X_hi Z_hi + X_hi Z_lo + X_lo Z_hi
+//   Gram      S'[p][i] over 32-feature k-steps, v_mfma_f32_16x16x32_f16:   X_hi Z_hi + X_hi Z_lo  (+ X_lo Z_hi: TVAE_GRAM_PRODUCTS)
 //   gradient  acc^T[d][i] += X^T[d][p] (s_p E[p][i]), K = the tile's 16 points, v_mfma_f32_32x32x16_f16 on tiles of
 //             32 features x 32 rows:   X_hi E_hi + X_lo E_hi + X_hi E_lo
 // E goes through a 2 RT KiB LDS buffer (the producer lanes hold points x rows the way the Gram left them, the gradient's
@@ -54,6 +54,10 @@ __global__ __launch_bounds__(64 * N16_WAVES, N16_WPE(KBN, RT)) void mmd_n16_kern
     using L = N16Lds<KBN, RT>;
     constexpr int DPAD = 32 * KBN, ROWS = 16 * RT, RB = RT / 2;      // ROWS: per wave; RB: 32-row blocks of the gradient
     constexpr int ROWS_WG = N16_WAVES * ROWS, PT = N16_PT, STEP_P = PT * TILE_P;
+    // Gram products (mmd_common.h, TVAE_GRAM_PRODUCTS): the error of the two-product form grows as the width shrinks (the
+    // 1 / D^2 in t no longer hides it; measured gradient error against fp64: 2e-7 at D = 192, 6e-7 at 77, 2.4e-6 at 32,
+    // 1e-5 at 8), so widths up to 64 keep all three
+    constexpr int GP = KBN >= 3 ? TVAE_GRAM_PRODUCTS : 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
     const unsigned sm_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -243,13 +247,16 @@ __global__ __launch_bounds__(64 * N16_WAVES, N16_WPE(KBN, RT)) void mmd_n16_kern
 #pragma unroll
         for (int s = 0; s < KBN; ++s) {
             const f16x8_t ab = *reinterpret_cast<const f16x8_t*>(xs + gram_off + 2048 * s);
-            const f16x8_t al = *reinterpret_cast<const f16x8_t*>(xs + gram_off + 2048 * s + 1024);
+            f16x8_t al;
+            if constexpr (GP == 3) al = *reinterpret_cast<const f16x8_t*>(xs + gram_off + 2048 * s + 1024);
 #pragma unroll
             for (int t = 0; t < RT; ++t) S[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab, zreg[t][s], s == 0 ? zero : S[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < RT; ++t) S[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ab, zlo[t][s], S[t], 0, 0, 0);
+            if constexpr (GP == 3) {
 #pragma unroll
-            for (int t = 0; t < RT; ++t) S[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, zreg[t][s], S[t], 0, 0, 0);
+                for (int t = 0; t < RT; ++t) S[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, zreg[t][s], S[t], 0, 0, 0);
+            }
         }
         PHASE_MARK(2);
 

@@ -406,14 +406,18 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(ab[s][pt], zreg[t][s], s == 0 ? zero : S[pt][t]);
             if constexpr (SPLIT) {
+#if TVAE_GRAM_PRODUCTS >= 2
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(ab[s][pt], zlo[t][s], S[pt][t]);
+#endif
+#if TVAE_GRAM_PRODUCTS == 3
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(al[s][pt], zreg[t][s], S[pt][t]);
+#endif
             }
 #ifndef TVAE_DEBUG_NO_E
             if constexpr (WITH_E) e_slice(s);
@@ -880,14 +884,18 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(ab[s][pt], zreg[t][s], s == 0 ? zero : S[pt][t]);
             if constexpr (SPLIT) {
+#if TVAE_GRAM_PRODUCTS >= 2
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(ab[s][pt], zlo[t][s], S[pt][t]);
+#endif
+#if TVAE_GRAM_PRODUCTS == 3
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(al[s][pt], zreg[t][s], S[pt][t]);
+#endif
             }
             if constexpr (WITH_E) e_slice(s);
             // the MFMAs of block s are issued (their operand reads have completed) before its refill
