@@ -37,8 +37,8 @@ extern "C" {
 /* tvae_mmd_* only: fp32 inputs with every product on the fp32-input matrix instruction (v_mfma_f32_16x16x4_f32).
  * Plain TVAE_F32 gives the MMD the same accuracy class (1e-5 of the fp32 reference on loss and gradient, fp32
  * accumulation, fp64 reductions) but, for latent_size <= 1024 (latent_size <= 192: from 1024 points on), forms each
- * fp32 product from three fp16 matrix-core products of scaled hi/lo halves (22 significant bits per operand), at
- * several times the speed. */
+ * fp32 product from two (Gram: row operand hi + lo, column operand hi) or three (gradient) fp16 matrix-core products of
+ * scaled hi/lo halves, at several times the speed (measured error against fp64: 1e-7 .. 5e-7). */
 #define TVAE_F32_STRICT 2
 
 #define TVAE_OK 0
@@ -144,7 +144,7 @@ int tvae_decode_bwd(const void* d_recon, const void* latent, const void* Wd,
  *   d_z    (n_rows, D) out, nullable: grad_scale * sum-form gradient for the local rows,
  *          complete (needs no exchange):  pass grad_scale = 4 n / (B N^2 D^2) for
  *          d reg_loss / d latent  (SURVEY.md 8a).  Written in `dtype`.
- * Any D: fused tile kernels up to 1024 (TVAE_F32 inputs: three fp16 hi/lo products per fp32 product on the 16-bit
+ * Any D: fused tile kernels up to 1024 (TVAE_F32 inputs: two or three fp16 hi/lo products per fp32 product on the 16-bit
  * matrix cores, D <= 192 from 1024 points on; TVAE_BF16 inputs wider than 192: one bf16 product; TVAE_F32_STRICT and
  * everything else: fp32-input MFMA), strip-wise through the projection GEMM beyond.  n_total < 2^30. */
 int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad);
