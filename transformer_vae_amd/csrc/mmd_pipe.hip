@@ -641,7 +641,10 @@ template <int KB, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
     using L = PipeLds<KB, SPLIT>;
     constexpr int P = L::P, PT = L::PT, RT = L::RT, TPW = L::TPW, SW = L::SW, DPAD = 4 * SW;
-    constexpr int NE = 4 * TPW, DPS = 2, SPB = 64 / P;       // SPB: steps per 64-point block
+    // with the two-product Gram (mmd_common.h) a sum-only launch never reads the lo copy of the columns: one DMA
+    // instruction per feature block instead of the hi + lo pair
+    constexpr bool HI_ONLY = SPLIT && TVAE_GRAM_PRODUCTS < 3;
+    constexpr int NE = 4 * TPW, DPS = HI_ONLY ? 1 : 2, SPB = 64 / P;       // SPB: steps per 64-point block
     constexpr int NORM4_OFF = L::EBUF_OFF;                    // [4 ring][4 waves][64] floats, in the (unused) E buffers
     static_assert(2 * L::EBUF_ONE_B >= 4 * 4 * 64 * 4, "norm ring does not fit the E buffers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -760,7 +763,8 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
         dma4(uniform_ptr(X.nrm), (unsigned)lane * 4u, dst);
     };
     auto dma_block = [&](const Src& X, int b, int s) {
-        dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, dma_voff_b, smem_byte + xbuf_byte(b) + 2048u * s);
+        if constexpr (HI_ONLY) dma16(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, smem_byte + xbuf_byte(b) + 2048u * s);
+        else dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, dma_voff_b, smem_byte + xbuf_byte(b) + 2048u * s);
     };
 
     f32x4 S[PT][RT], own[TPW];
