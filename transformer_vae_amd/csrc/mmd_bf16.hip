@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
     using L = Bf16Lds<KB, RT, GRAD, SPLIT>;
     static_assert(GRAD || RT == 2, "the symmetric y-y enumeration assumes 32-row blocks");
     constexpr int SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;     // NI: 16-feature blocks per slice
-    constexpr int DPS = SPLIT ? 4 : 2;                        // DMA instructions per 32-feature block pair
+    // (with the two-product Gram of mmd_common.h a sum-only launch never reads the lo copy of the columns)
+    constexpr bool NEED_LO = SPLIT && (GRAD || TVAE_GRAM_PRODUCTS == 3);
+    constexpr int DPS = NEED_LO ? 4 : 2;                      // DMA instructions per 32-feature block pair
     constexpr int TPW = L::TPW, ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
     const unsigned dma_voff_b = dma_voff + 16u * DPAD * 2u - 1024u;      // second point tile, see dma16_pair
     auto dma_pair = [&](const Src& X, int s) {       // features [32 s, 32 s + 32) of both point tiles (SPLIT: hi, then lo)
         dma16_pair(reinterpret_cast<const float*>(X.hi + 32 * s), dma_voff, dma_voff_b, xs_byte + 2048u * s);
-        if constexpr (SPLIT)
+        if constexpr (NEED_LO)
             dma16_pair(reinterpret_cast<const float*>(X.lo + 32 * s), dma_voff, dma_voff_b,
                        xs_byte + (unsigned)L::SLICE_B + 2048u * s);
     };

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(64 * N16_WAVES, N16_WPE(KBN, RT)) void mmd_n16_kern
             const int j = j0 + wave;
             if (j < PT * KBN) {
                 const int u = j / KBN, s = j - u * KBN;
-                dma16_pair(X + (u * TILE_P * DPAD + 32 * s) / 2, dma_voff, dma_voff_lo, sm_byte + (unsigned)(buf * L::STEP_B + 2048 * j));
+                // (a workgroup without gradient never reads the lo copy under the two-product Gram)
+                if (GP == 3 || do_grad) dma16_pair(X + (u * TILE_P * DPAD + 32 * s) / 2, dma_voff, dma_voff_lo, sm_byte + (unsigned)(buf * L::STEP_B + 2048 * j));
+                else dma16(X + (u * TILE_P * DPAD + 32 * s) / 2, dma_voff, sm_byte + (unsigned)(buf * L::STEP_B + 2048 * j));
             }
         }
     };
