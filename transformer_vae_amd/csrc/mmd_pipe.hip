@@ -639,12 +639,14 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 template <int KB, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
-    using L = PipeLds<KB, SPLIT>;
+    // With the two-product Gram (mmd_common.h) a sum-only launch never reads the lo copy of the columns, so split mode
+    // takes the bf16 instantiation's LDS layout and 32-point steps (two point tiles of the hi copy per 2 KiB block)
+    // with fp16 arithmetic and the row side's second product: half the barriers, exchanges and scalar bookkeeping per
+    // point.  LS: the hi | lo piece layout of the 16-point split steps (three-product builds only).
+    constexpr bool LS = SPLIT && TVAE_GRAM_PRODUCTS == 3;
+    using L = PipeLds<KB, LS>;
     constexpr int P = L::P, PT = L::PT, RT = L::RT, TPW = L::TPW, SW = L::SW, DPAD = 4 * SW;
-    // with the two-product Gram (mmd_common.h) a sum-only launch never reads the lo copy of the columns: one DMA
-    // instruction per feature block instead of the hi + lo pair
-    constexpr bool HI_ONLY = SPLIT && TVAE_GRAM_PRODUCTS < 3;
-    constexpr int NE = 4 * TPW, DPS = HI_ONLY ? 1 : 2, SPB = 64 / P;       // SPB: steps per 64-point block
+    constexpr int NE = 4 * TPW, DPS = 2, SPB = 64 / P;       // SPB: steps per 64-point block
     constexpr int NORM4_OFF = L::EBUF_OFF;                    // [4 ring][4 waves][64] floats, in the (unused) E buffers
     static_assert(2 * L::EBUF_ONE_B >= 4 * 4 * 64 * 4, "norm ring does not fit the E buffers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
 
     const int dma_r = lane >> 2, dma_c = (lane & 3) ^ (2 * ((lane >> 4) & 1));
     const unsigned dma_voff = (unsigned)(dma_r * DPAD + 8 * dma_c) * 2u;
-    const unsigned dma_voff_b = SPLIT ? dma_voff + (unsigned)(reinterpret_cast<const char*>(a.cols_lo[0]) - reinterpret_cast<const char*>(a.cols[0])) - 1024u
+    const unsigned dma_voff_b = LS ? dma_voff + (unsigned)(reinterpret_cast<const char*>(a.cols_lo[0]) - reinterpret_cast<const char*>(a.cols[0])) - 1024u
                                       : dma_voff + 16u * DPAD * 2u - 1024u;
     const int gram_off = 16 * (4 * i16 + (g ^ (2 * ((i16 >> 2) & 1))));
 
@@ -763,8 +765,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
         dma4(uniform_ptr(X.nrm), (unsigned)lane * 4u, dst);
     };
     auto dma_block = [&](const Src& X, int b, int s) {
-        if constexpr (HI_ONLY) dma16(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, smem_byte + xbuf_byte(b) + 2048u * s);
-        else dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, dma_voff_b, smem_byte + xbuf_byte(b) + 2048u * s);
+        dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, dma_voff_b, smem_byte + xbuf_byte(b) + 2048u * s);
     };
 
     f32x4 S[PT][RT], own[TPW];
@@ -788,13 +789,13 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
     // DMA in flight on entry: the 1 + DPS KB instructions of the tile in the OTHER buffer; everything older has to land.
     // (gram_prefetch: the k-step 0 operands of the next interval's Gram, read ahead of the barrier -- the tile is
     // wave-private and has landed; measured neutral, 2.9 -> 3.1 ms at N = 32 768, kept for symmetry with the gradient kernel)
-    h16x8_t nab[PT], nal[SPLIT ? PT : 1];
+    h16x8_t nab[PT], nal[LS ? PT : 1];
     auto gram_prefetch = [&](int b) {
         const char* xs = sm + xbuf_byte(b);
         wait_vmcnt_n(1 + DPS * KB);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            if constexpr (SPLIT) {
+            if constexpr (LS) {
                 nab[pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off);
                 nal[pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 1024);
             } else {
@@ -817,16 +818,16 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
             cn = *reinterpret_cast<const f32x4*>(sm + NORM4_OFF + ((ring_e * 4 + wave) * 64 + 16 * my_pt + 4 * g) * 4);
         }
         constexpr int GD = KB < TVAE_PIPE_GD ? KB : TVAE_PIPE_GD;
-        h16x8_t ab[KB][PT], al[SPLIT ? KB : 1][PT];
+        h16x8_t ab[KB][PT], al[LS ? KB : 1][PT];
         auto rd = [&](int sr) {
             if (PRE && sr == 0) {
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) { ab[0][pt] = nab[pt]; if constexpr (SPLIT) al[0][pt] = nal[pt]; }
+                for (int pt = 0; pt < PT; ++pt) { ab[0][pt] = nab[pt]; if constexpr (LS) al[0][pt] = nal[pt]; }
                 return;
             }
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                if constexpr (SPLIT) {
+                if constexpr (LS) {
                     ab[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 2048 * sr);
                     al[sr][pt] = *reinterpret_cast<const h16x8_t*>(xs + gram_off + 2048 * sr + 1024);
                 } else {
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
 
 template <int KB, bool SPLIT>
 int launch_pipe_sum(const MmdArgs& a, int nblocks, hipStream_t s) {
-    constexpr int lds_bytes = PipeLds<KB, SPLIT>::BYTES;
+    constexpr int lds_bytes = PipeLds<KB, SPLIT && TVAE_GRAM_PRODUCTS == 3>::BYTES;      // the kernel's LS
     static PerDeviceOnce once;
     TVAE_CHECK_HIP(per_device_once(once, [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_pipe_sum_kernel<KB, SPLIT>),
