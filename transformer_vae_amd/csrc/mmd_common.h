@@ -74,6 +74,9 @@ constexpr float SPLIT_E_SCALE = 4096.f;
 #ifndef TVAE_GRAM_PRODUCTS
 #define TVAE_GRAM_PRODUCTS 2
 #endif
+#ifndef TVAE_GRAD_PRODUCTS
+#define TVAE_GRAD_PRODUCTS 3      // gradient entry: X_hi E_hi + X_lo E_hi + X_hi E_lo (2: X_lo E_hi dropped, experiment)
+#endif
 struct SplitScales { float s, inv_s2, grad_unscale; };
 __device__ __forceinline__ SplitScales split_scales(unsigned amax_bits) {
     const float amax = __uint_as_float(amax_bits);

@@ -481,9 +481,11 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 #pragma unroll
                 for (int rbk = 0; rbk < 2; ++rbk)
                     acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
+#if TVAE_GRAD_PRODUCTS == 3
 #pragma unroll
                 for (int rbk = 0; rbk < 2; ++rbk)
                     acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
+#endif
 #pragma unroll
                 for (int rbk = 0; rbk < 2; ++rbk)
                     acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bl[rbk]), acc[blk][rbk], 0, 0, 0);
