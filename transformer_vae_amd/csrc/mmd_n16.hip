@@ -1,22 +1,24 @@
 // MMD tile kernel for NARROW latents (D <= 192) on the 16-bit matrix cores: fp32 inputs as scaled fp16 pairs hi + lo
-// (mmd_common.h, split_scales), three matrix products per fp32 product -- the split-fp16 mode of DESIGN 4.1d for the
-// shapes the reference actually ships (latent_size 77).
+// (mmd_common.h, split_scales) -- the split-fp16 mode of DESIGN 4.1d / 4.1f for the shapes the reference actually ships
+// (latent_size 77).
 //
-// Each of the four waves of a workgroup owns 16 RT rows with ALL features in registers (no exchange of partial
-// products); DPAD = 32 KBN features.  RT = 2 (32 rows per wave): rows and accumulators have to leave room for two to
-// four waves per SIMD, which is what covers one wave's waits (LDS round trip of E, matrix results) with the others'
-// instructions.  The four waves SHARE the column tiles: one LDS-DMA of a tile serves 64 RT
-// rows, and one barrier per tile hands the double buffer over.  (A first version with one wave per workgroup, every
-// wave streaming its own tiles, ran at the pace of the L2 -> LDS path: 124 us at N = 5 120, D = 77, about 30 GB/s
-// per CU, the guide's Infinity-Cache gather rate.)
-//   Gram      S'[p][i] over 32-feature k-steps, v_mfma_f32_16x16x32_f16:   X_hi Z_hi + X_hi Z_lo  (+ X_lo Z_hi: TVAE_GRAM_PRODUCTS)
-//   gradient  acc^T[d][i] += X^T[d][p] (s_p E[p][i]), K = the tile's 16 points, v_mfma_f32_32x32x16_f16 on tiles of
+// Each of the four waves of a workgroup owns 32 rows (RT = 2 row tiles) with ALL features in registers (no exchange of
+// partial products); DPAD = 32 KBN features.  Rows and accumulators leave room for two to four waves per SIMD, which is
+// what covers one wave's waits (LDS round trip of E, matrix results) with the others' instructions.  The four waves
+// SHARE the column tiles: one LDS-DMA of a step serves all 128 rows, and one barrier per step (two 16-point tiles)
+// hands the double buffer over.  (A first version with one wave per workgroup, every wave streaming its own tiles, ran
+// at the pace of the L2 -> LDS path: 124 us at N = 5 120, D = 77, about 30 GB/s per CU, the guide's Infinity-Cache
+// gather rate.)
+//   Gram      S'[p][i] over 32-feature k-steps, v_mfma_f32_16x16x32_f16:   X_hi Z_hi + X_hi Z_lo  (+ X_lo Z_hi up to 64
+//             features: TVAE_GRAM_PRODUCTS in mmd_common.h)
+//   gradient  acc^T[d][i] += X^T[d][p] (s_p E[p][i]), K = a tile's 16 points, v_mfma_f32_32x32x16_f16 on tiles of
 //             32 features x 32 rows:   X_hi E_hi + X_lo E_hi + X_hi E_lo
-// E goes through a 2 RT KiB LDS buffer (the producer lanes hold points x rows the way the Gram left them, the gradient's
-// B operand wants eight points of one row per lane).  Point tiles are double buffered: the LDS-DMA of tile k + 1 is
-// issued at the top of tile k, one M0 set-up per hi + lo pair (mmd_pipe.hip).
+// E goes through a per-wave 2 KiB LDS buffer (the producer lanes hold points x rows the way the Gram left them, the
+// gradient's B operand wants eight points of one row per lane).  Steps are double buffered: the LDS-DMA of step k + 1 is
+// issued at the top of step k, one M0 set-up per hi + lo pair (mmd_pipe.hip); a workgroup without gradient fetches the
+// hi copy alone when the Gram does not read lo.
 // Workgroups [0, nwg0) take problem 0 (z rows against both column sets, with the gradient when GRAD), the rest
-// problem 1 (y rows against the priors, sum only, symmetric enumeration on blocks of 16 RT points when a.sym).
+// problem 1 (y rows against the priors, sum only, symmetric enumeration on 128-point blocks when a.sym).
 #include <type_traits>
 
 #include "mmd_common.h"
@@ -30,11 +32,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int N16_WAVES = 4;
-constexpr int N16_PT = 2;
+constexpr int N16_PT = 2;          // 16-point tiles per step (one barrier and one round of LDS-DMA per step)
 #ifndef TVAE_N16_RT_SMALL
 #define TVAE_N16_RT_SMALL 2        // row tiles per wave for KBN <= 2 (4: measured 6 % slower at N = 8 192, D = 64 and 30 % at N = 2 048, D = 32)
 #endif
-constexpr int N16_WPE(int kbn, int rt) { return rt == 2 ? (kbn == 1 ? 4 : (kbn <= 3 ? 3 : 2)) : (kbn == 1 ? 3 : 2); }   // waves per SIMD asked of hipcc          // 16-point tiles per step (one barrier and one round of LDS-DMA per step)
+// waves per SIMD asked of hipcc (registers per wave: 512 / that)
+constexpr int N16_WPE(int kbn, int rt) { return rt == 2 ? (kbn == 1 ? 4 : (kbn <= 3 ? 3 : 2)) : (kbn == 1 ? 3 : 2); }
 
 template <int KBN, int RT>
 struct N16Lds {
