@@ -131,7 +131,7 @@ class EncoderDecoderVAE(nn.Module):
         over the R ranks while each rank holds only its rows' share of the global loss gradient; the local latent
         gradient is multiplied by R so that the averaged result equals the single-process global-batch gradient.
         Pass False only when gradients are summed, not averaged, across ranks.
-        ``mmd_strict_fp32``: fp32 latents on the fp32-input matrix instruction instead of the default three fp16
+        ``mmd_strict_fp32``: fp32 latents on the fp32-input matrix instruction instead of the default two or three fp16
         matrix-core products per fp32 product (same 1e-5 accuracy class, several times faster)."""
         super().__init__()
         if mmd_scope not in ("local", "global"):

@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
 // ---- host side ------------------------------------------------------------------------
 struct Plan {
     int bf16_tiles;   // 1: bf16 copies + mmd_bf16_kernel<KB = DPAD / 128> (bf16 inputs, or split fp32 inputs, D > 192)
-    int split;        // 1 (with bf16_tiles): fp32 inputs as hi + lo fp16 copies, three products per fp32 product
+    int split;        // 1 (with bf16_tiles): fp32 inputs as hi + lo fp16 copies, two (Gram) or three (gradient) products per fp32 product
     int pipe;         // 1 (with bf16_tiles): the gradient launch runs mmd_pipe_kernel (64 rows, software-pipelined)
     int pipe_sum;     // 1 (with bf16_tiles): the sum-only launches run mmd_pipe_sum_kernel (64-row blocks too)
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
@@ -822,7 +822,7 @@ const Shape* pick_shape(int64_t D) {
 }
 
 // Kernel family of a call.  Wide latents (192 < D <= 1024): bf16 inputs run on the bf16 matrix cores; fp32 inputs run
-// there too, as hi + lo bf16 pairs with three products per fp32 product (MODE_SPLIT, same 1e-5 accuracy class as the
+// there too, as scaled hi + lo fp16 pairs with two or three products per fp32 product (MODE_SPLIT, same 1e-5 accuracy class as the
 // fp32-input MFMA at 16x its rate), unless the caller asks for TVAE_F32_STRICT.  Narrow latents (D <= 192): fp32
 // inputs run the same split arithmetic on the single-wave kernel of mmd_n16.hip; bf16 inputs and TVAE_F32_STRICT stay
 // on the single-wave fp32 kernels (bf16 inputs are widened exactly).
@@ -917,7 +917,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     if (bf16_tiles) {
         const int64_t col_bytes = 2ll * p->n_pad * p->DPAD * (p->split ? 4 : 2);
         if (col_bytes > (64ll << 20)) {
-            // chunk size: ~24 MB for the one-product kernels (a step lasts ~1 us); the split kernels do three times the
+            // chunk size: ~24 MB for the one-product kernels (a step lasts ~1 us); the split kernels do two to three times the
             // matrix work per byte (~5 us per step) and are at their best with ~96 MB (cfg4 size: 1 split 1 435 ms,
             // 4 -> 1 353, 8 -> 1 252, 16 -> 1 217, 32 -> 1 225, 63 -> 1 232)
             const int64_t chunk = p->split ? (96ll << 20) : (24ll << 20);

@@ -73,7 +73,7 @@ struct Bf16Lds {
     static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses the exchange buffer");
 };
 
-// SPLIT (fp32 inputs, "three fp16 products per fp32 product"): every fp32 value v is held as hi = fp16(s v) and
+// SPLIT (fp32 inputs, two (Gram, TVAE_GRAM_PRODUCTS) or three (gradient) fp16 products per fp32 product): every fp32 value v is held as hi = fp16(s v) and
 // lo = fp16(s v - hi), s a power of two that puts the largest |v| of the call at 2^11 (22 significant bits, error
 // <= 2^-22 of the largest value: the fp32 input MFMA's own class).  The Gram is X_hi Z_hi + X_hi Z_lo + X_lo Z_hi and
 // the gradient product X_hi^T E_hi + X_lo^T E_hi + X_hi^T E_lo (E in (-1, 0] scaled by 2^12), all accumulated in fp32

@@ -153,7 +153,7 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 #endif
 
 // bf16 matrix-core tile kernels (mmd_bf16.hip); kb = padded dimension / 128 (2..8)
-// split: fp32 values as hi + lo bf16 pairs, three products per fp32 product; rt = 16-row tiles per workgroup (2, or 4
+// split: fp32 values as scaled hi + lo fp16 pairs, two or three products per fp32 product; rt = 16-row tiles per workgroup (2, or 4
 // for the split gradient launch with kb <= 6)
 int launch_mmd_bf16(bool grad, bool split, int kb, int rt, const MmdArgs& a, int nblocks, hipStream_t s);
 // software-pipelined gradient kernel of the 16-bit matrix-core modes, 64 rows per workgroup (mmd_pipe.hip); kb = 2..6

@@ -185,7 +185,7 @@ class _LatentDecode(torch.autograd.Function):
 
 
 def _mmd_code(dt: torch.dtype, strict_fp32: bool) -> int:
-    """dtype code of a tvae_mmd_* call: fp32 inputs run the split-fp16 products (three matrix-core products per fp32
+    """dtype code of a tvae_mmd_* call: fp32 inputs run the split-fp16 products (two or three matrix-core products per fp32
     product, same 1e-5 accuracy class) unless ``strict_fp32`` asks for the fp32-input matrix instruction."""
     if dt == torch.float32 and strict_fp32:
         return _lib.TVAE_F32_STRICT
