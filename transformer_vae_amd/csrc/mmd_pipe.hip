@@ -347,7 +347,11 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
                     ev = ok ? (big ? ex : ev) : 0.f;
                     qv = ok ? (big ? ex + tt[el] : qv) : 0.f;
                 }
+#ifdef TVAE_QFORM_PROTO      // experiment (DESIGN 9, Q-form gradient): gradient and row sums carry Q = E + t, one product
+                e[j][r] = qv;
+#else
                 e[j][r] = ev;
+#endif
                 q[j][r] = qv;
             }
             if (s != FIN) return;
@@ -481,14 +485,16 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 #pragma unroll
                 for (int rbk = 0; rbk < 2; ++rbk)
                     acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
-#if TVAE_GRAD_PRODUCTS == 3
+#if TVAE_GRAD_PRODUCTS == 3 && !defined(TVAE_QFORM_PROTO)
 #pragma unroll
                 for (int rbk = 0; rbk < 2; ++rbk)
                     acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
 #endif
+#ifndef TVAE_QFORM_PROTO
 #pragma unroll
                 for (int rbk = 0; rbk < 2; ++rbk)
                     acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bl[rbk]), acc[blk][rbk], 0, 0, 0);
+#endif
             } else {
                 const h16x8_t A1 = __builtin_bit_cast(h16x8_t, __builtin_shufflevector(gh[blk][0], gh[blk][1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
