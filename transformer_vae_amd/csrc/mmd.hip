@@ -581,7 +581,8 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                                                        TC* __restrict__ yp, float* __restrict__ zn,
                                                        float* __restrict__ yn, float* __restrict__ colpart,
                                                        int rows_per_wave, int nwaves, int lo, int hi, int nw0, int nw1,
-                                                       long long lo_off, const unsigned* __restrict__ split_amax) {
+                                                       long long lo_off, const unsigned* __restrict__ split_amax,
+                                                       float* __restrict__ colpart3) {
     const float scale = SPLIT ? split_scales(*split_amax).s : 1.f;
     const int lane = threadIdx.x & 63;
     const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -591,9 +592,9 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
     TC* __restrict__ dst = set ? yp : zp;
     float* __restrict__ nrm = set ? yn : zn;
     const int NJ = (DPAD + 63) / 64;      // 64-column groups per row (<= 16)
-    float csum[16];
+    float csum[16], csum3[16];      // csum3 (Q-form gradient only): partial sums of |row|^2 row
 #pragma unroll
-    for (int j = 0; j < 16; ++j) csum[j] = 0.f;
+    for (int j = 0; j < 16; ++j) { csum[j] = 0.f; csum3[j] = 0.f; }
     // rows are cut into [0, lo), [lo, hi), [hi, n_pad) -- the local row range of this call is [lo, hi) -- and
     // each segment into chunks of rows_per_wave: waves nw0 .. nw0 + nw1 - 1 hold exactly the local rows
     int r0, r1;
@@ -633,30 +634,108 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                     }
                     sq = wave_sum(sq);
                     if (lane == 0) nrm[rr] = sq;
+                    if (colpart3) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) csum3[j] = fmaf(sq, v[u][j], csum3[j]);
+                    }
                 }
             }
         }
     } else {
         for (int row = r0; row < r1; ++row) {
-            float sq = 0.f;
+            float sq = 0.f, vr[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int c = lane + 64 * j;
+                vr[j] = 0.f;
                 if (j < NJ && c < DPAD) {
                     const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
                     prep_store<TC, SPLIT>(dst, (long long)row * DPAD + c, lo_off, v, scale);    // TC == bf16 without SPLIT only with T == bf16: exact
                     csum[j] += v;
                     sq = fmaf(v, v, sq);
+                    vr[j] = v;
                 }
             }
             sq = wave_sum(sq);
             if (lane == 0) nrm[row] = sq;
+            if (colpart3) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) csum3[j] = fmaf(sq, vr[j], csum3[j]);
+            }
         }
     }
     float* cp = colpart + ((long long)set * nwaves + wg) * DPAD;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         if (j < NJ && lane + 64 * j < DPAD) cp[lane + 64 * j] = csum[j];
+    if (colpart3) {
+        float* cp3 = colpart3 + ((long long)set * nwaves + wg) * DPAD;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < NJ && lane + 64 * j < DPAD) cp3[lane + 64 * j] = csum3[j];
+    }
+}
+
+// ---- Q-form gradient (split pipelined path): E = -t + Q(t), the part linear in t in closed form ----------------------
+//   sum_p s_p E_kp x_p = -(1/D^2) [ m3 + |z_k|^2 shift - 2 M2 z_k ] + sum_p s_p Q_kp x_p
+//   sum_p s_p E_kp     = -(1/D^2) [ A_z - A_y - 2 shift . z_k ]     + sum_p s_p Q_kp          (sum_p s_p = 0)
+// with m3 = sum_z |z|^2 z - sum_y |y|^2 y, shift = sum z - sum y, M2 = Z^T Z - Y^T Y, A = sums of squared norms.
+// For the shapes that matter t ~ 2 / D, so Q ~ t^2 / 2 is ~1e-3 of E and ONE fp16 product carries the tile kernel's share of
+// the gradient at the accuracy of the fp32 kernel.  Valid while every t of the call is below the
+// polynomial range: the flag kernel bounds t by 4 max |.|^2 / D^2 on the device, and tile kernel and finalize read it.
+struct QFlag { unsigned on; unsigned pad; double az, ay; };      // az, ay: sums of squared norms over all points
+
+__global__ __launch_bounds__(1024) void mmd_qflag_kernel(const float* __restrict__ zn, const float* __restrict__ yn, int n_total,
+                                                          int D, QFlag* __restrict__ out) {
+    __shared__ double rz[16], ry[16];
+    __shared__ float rm[16];
+    double az = 0.0, ay = 0.0;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < n_total; i += 1024) {
+        const float a = zn[i], b = yn[i];
+        az += (double)a; ay += (double)b;
+        mx = fmaxf(mx, fmaxf(a, b));
+    }
+    az = wave_sum(az); ay = wave_sum(ay);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) { rz[threadIdx.x >> 6] = az; ry[threadIdx.x >> 6] = ay; rm[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sz = 0.0, sy = 0.0;
+        float m = 0.f;
+        for (int k = 0; k < 16; ++k) { sz += rz[k]; sy += ry[k]; m = fmaxf(m, rm[k]); }
+        // t <= (|x| + |z|)^2 / D^2 <= 4 max|.|^2 / D^2; half the polynomial range leaves room for rounding (NaN: off)
+        const float bound = 4.f * m / ((float)D * (float)D);
+        out->on = (bound < 0.5f * EM1_POLY_MAX) ? 1u : 0u;
+        out->pad = 0u;
+        out->az = sz; out->ay = sy;
+    }
+}
+
+// m3[c] from the per-wave partials (fp64 accumulate, fixed order)
+__global__ __launch_bounds__(256) void mmd_m3_kernel(const float* __restrict__ colpart3, int nwaves, int DPAD, float* __restrict__ m3) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= DPAD) return;
+    double sz = 0.0, sy = 0.0;
+#pragma unroll 8
+    for (int w = 0; w < nwaves; ++w) {
+        sz += (double)colpart3[(long long)w * DPAD + c];
+        sy += (double)colpart3[((long long)nwaves + w) * DPAD + c];
+    }
+    m3[c] = (float)(sz - sy);
+}
+
+// M2 = Z^T Z - Y^T Y (in place over the first) with shift appended as column D: row r of the D x (D + 1) matrix the
+// row product below multiplies by, so that column D of its result is shift . z_k
+__global__ __launch_bounds__(256) void mmd_m2_fix_kernel(float* __restrict__ m2z, const float* __restrict__ m2y, const float* __restrict__ shift,
+                                                          int D, int ld) {
+    const long long total = (long long)D * (D + 1);
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx / (D + 1)), c = (int)(idx - (long long)r * (D + 1));
+        const long long at = (long long)r * ld + c;
+        m2z[at] = c < D ? m2z[at] - m2y[at] : shift[r];
+    }
 }
 
 // Column moments from the per-wave partials (fp64 accumulate, fixed order):
@@ -710,6 +789,8 @@ struct FinalArgs {
     const unsigned* split_amax;   // split kernels: the gradient slabs carry 2^12 s G (split_scales); else null
     // closed-form linear part: squared norms of all points, the local rows, the column-moment dot products
     const float* zn; const float* yn; int n_total; const double* dots; int ndots;
+    // Q-form gradient (null: off): the flag, m3, and P = Z_rows [M2 | shift] (row stride ldP, column D = shift . z_k)
+    const QFlag* qflag; const float* m3; const float* P; int ldP;
 };
 
 template <typename T>
@@ -769,6 +850,9 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
     if (!f.d_z) return;
     T* out = static_cast<T*>(f.d_z);
     const long long total = (long long)f.n_rows * f.D;
+    const bool qf = f.qflag != nullptr && f.qflag->on != 0;      // the slabs carry the Q sums: add the closed-form linear part
+    const double inv_d2 = 1.0 / ((double)f.D * (double)f.D);
+    const double a_s = qf ? f.qflag->az - f.qflag->ay : 0.0;
     for (long long idx = (long long)blockIdx.x * 256 + tid; idx < total; idx += (long long)gridDim.x * 256) {
         const int row = (int)(idx / f.D), c = (int)(idx - (long long)row * f.D);
         double rsum = 0.0;
@@ -780,7 +864,13 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
         }
         if (f.split_amax) gsum *= split_scales(*f.split_amax).grad_unscale;       // a power of two: exact
         const double zv = (double)to_f32(static_cast<const T*>(f.z_src)[((long long)f.row_offset + row) * f.D + c]);
-        const double v = f.grad_scale * (-zv * rsum + (double)f.shift[c] + (double)gsum);
+        double glin = 0.0;
+        if (qf) {
+            const float* pr = f.P + (long long)row * f.ldP;
+            rsum -= inv_d2 * (a_s - 2.0 * (double)pr[f.D]);
+            glin = -inv_d2 * ((double)f.m3[c] + (double)f.zn[f.row_offset + row] * (double)f.shift[c] - 2.0 * (double)pr[c]);
+        }
+        const double v = f.grad_scale * (-zv * rsum + (double)f.shift[c] + (double)gsum + glin);
         out[idx] = from_f32<T>((float)v);
     }
 }
@@ -794,10 +884,12 @@ struct Plan {
     int RT, row_blocks_g;   // gradient launch: 16-row tiles per workgroup and its row blocks (32-row blocks otherwise)
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
     int n16;                // 1 (with split, without bf16_tiles): mmd_n16_kernel, narrow latents on the fp16 matrix cores
+    int qform;              // 1 (with pipe and split): Q-form gradient, linear part in closed form (see QFlag)
+    int ldq;                // row stride of M2 and P (D + 1 columns, padded)
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
     int sp_major;     // 1: split-major workgroup order (see make_plan)
     int sync_epochs, sync_group, sync_groups;   // soft rendezvous of the gradient launch (sync_epochs == 0: off)
-    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, off_sync, off_amax, bytes;
+    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, off_sync, off_amax, off_col3, off_m3, off_m2, off_p, off_gslab, off_qflag, bytes;
 };
 
 // (padded dimension, waves per workgroup, 16-column blocks per wave); DPAD = WAVES * 16 * NB
@@ -814,6 +906,10 @@ const Shape kShapes[] = {{16, 1, 1}, {32, 1, 2}, {48, 1, 3}, {64, 1, 4}, {80, 1,
 #define TVAE_PIPE_SUM_BF16 1
 #endif
 constexpr bool kPipeSumBf16 = TVAE_PIPE_SUM_BF16 != 0;   // bf16 mode: sum-only launches on the pipelined kernel too
+#ifndef TVAE_QFORM
+#define TVAE_QFORM 1
+#endif
+constexpr bool kQForm = TVAE_QFORM != 0;        // Q-form gradient on the split pipelined path (0: E-form, three gradient products)
 constexpr int kPipeMaxKb = TVAE_PIPE_MAX_KB;    // pipelined gradient kernel up to this many feature blocks per wave (0: off)
 const Shape* pick_shape(int64_t D) {
     for (const Shape& sh : kShapes)
@@ -964,6 +1060,20 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
 #endif
     p->off_sync = take((int64_t)p->sync_groups * 8 * p->sync_epochs * 4);
     p->off_amax = take(p->split ? 256 + AMAX_BLOCKS * 4 : 0);      // the scale word, then the per-block maxima
+    p->qform = (kQForm && p->pipe && p->split && want_grad) ? 1 : 0;
+    p->ldq = (int)align_up(D + 1, 4);
+    p->off_col3 = take(p->qform ? (int64_t)2 * p->nwaves * p->DPAD * 4 : 0);
+    p->off_m3 = take(p->qform ? (int64_t)p->DPAD * 4 : 0);
+    p->off_m2 = take(p->qform ? (int64_t)2 * D * p->ldq * 4 : 0);                       // Z^T Z (then M2 | shift), Y^T Y
+    p->off_p = take(p->qform ? (int64_t)n_rows * p->ldq * 4 : 0);
+    int64_t gs_floats = 0;
+    if (p->qform) {
+        gs_floats = gemm_slab_floats((int)D, (int)D, (int)n_total);
+        const int64_t g2 = gemm_slab_floats((int)n_rows, (int)D + 1, (int)D);
+        if (g2 > gs_floats) gs_floats = g2;
+    }
+    p->off_gslab = take(gs_floats * 4);
+    p->off_qflag = take(p->qform ? 256 : 0);
     p->bytes = off;
     return true;
 }
@@ -1127,6 +1237,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     dim3 pgrid((nwaves + 3) / 4, 2);
     const long long lo_off = (long long)p.n_pad * p.DPAD;      // split: elements from the hi copy to the lo copy
     unsigned* split_amax = p.split ? reinterpret_cast<unsigned*>(ws + p.off_amax) : nullptr;
+    float* colpart3 = p.qform ? reinterpret_cast<float*>(ws + p.off_col3) : nullptr;
     if (p.split) {
         const long long count = (long long)n_total * D;
         long long ab = (count / 4 + 255) / 256;
@@ -1140,30 +1251,69 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
         TVAE_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL((mmd_prep_kernel<float, _Float16, true>), pgrid, dim3(256), 0, s, (const float*)z_all,
                            (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (_Float16*)zp, (_Float16*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, lo_off, split_amax);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, lo_off, split_amax, colpart3);
     }
     else if (dtype == TVAE_F32)
         hipLaunchKernelGGL((mmd_prep_kernel<float, float, false>), pgrid, dim3(256), 0, s, (const float*)z_all,
                            (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr, (float*)nullptr);
     else if (!p.bf16_tiles)
         hipLaunchKernelGGL((mmd_prep_kernel<bf16, float, false>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
                            (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr, (float*)nullptr);
     else
         hipLaunchKernelGGL((mmd_prep_kernel<bf16, bf16, false>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
                            (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (bf16*)zp, (bf16*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr);
+                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr, (float*)nullptr);
     TVAE_CHECK_HIP(hipGetLastError());
     double* dots = reinterpret_cast<double*>(ws + p.off_dots);
     const int ndots = (p.DPAD + 63) / 64;
     hipLaunchKernelGGL(mmd_moments_kernel, dim3(ndots), dim3(1024), 0, s, colpart, nwaves, nw0, nw1, p.DPAD, shift, dots);
     TVAE_CHECK_HIP(hipGetLastError());
 
+    // Q-form gradient: the closed-form linear part (see QFlag) -- flag and norm sums, m3, M2 = Z^T Z - Y^T Y with shift as
+    // an extra column, P = Z_rows [M2 | shift]; all on this stream, behind prep and moments
+    QFlag* qflag = nullptr;
+    float* m3 = nullptr;
+    float* pmat = nullptr;
+    if (p.qform) {
+        qflag = reinterpret_cast<QFlag*>(ws + p.off_qflag);
+        m3 = reinterpret_cast<float*>(ws + p.off_m3);
+        pmat = reinterpret_cast<float*>(ws + p.off_p);
+        float* m2z = reinterpret_cast<float*>(ws + p.off_m2);
+        float* m2y = m2z + (long long)D * p.ldq;
+        float* gslab = reinterpret_cast<float*>(ws + p.off_gslab);
+        hipLaunchKernelGGL(mmd_qflag_kernel, dim3(1), dim3(1024), 0, s, (const float*)zn, (const float*)yn, (int)n_total, (int)D, qflag);
+        TVAE_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(mmd_m3_kernel, dim3((p.DPAD + 255) / 256), dim3(256), 0, s, (const float*)colpart3, nwaves, p.DPAD, m3);
+        TVAE_CHECK_HIP(hipGetLastError());
+        GemmDesc g{};
+        g.bias = nullptr; g.epilogue = EPI_NONE; g.dtype = TVAE_F32; g.colsum_out = nullptr;
+        g.M = (int)D; g.N = (int)D; g.K = (int)n_total;
+        g.a_kmajor = true; g.b_kmajor = true;
+        g.amap = dense_rows(D); g.bmap = dense_rows(D); g.cmap = dense_rows(p.ldq);
+        g.slab = gslab; g.slab_floats = gemm_slab_floats((int)D, (int)D, (int)n_total);
+        g.A = z_all; g.B = z_all; g.C = m2z;
+        TVAE_PROPAGATE(gemm_launch(g, s));
+        g.A = y_all; g.B = y_all; g.C = m2y;
+        TVAE_PROPAGATE(gemm_launch(g, s));
+        hipLaunchKernelGGL(mmd_m2_fix_kernel, dim3(256), dim3(256), 0, s, m2z, (const float*)m2y, (const float*)shift, (int)D, p.ldq);
+        TVAE_CHECK_HIP(hipGetLastError());
+        GemmDesc h{};
+        h.bias = nullptr; h.epilogue = EPI_NONE; h.dtype = TVAE_F32; h.colsum_out = nullptr;
+        h.M = (int)n_rows; h.N = (int)D + 1; h.K = (int)D;
+        h.a_kmajor = false; h.b_kmajor = true;
+        h.amap = dense_rows(D); h.bmap = dense_rows(p.ldq); h.cmap = dense_rows(p.ldq);
+        h.slab = gslab; h.slab_floats = gemm_slab_floats((int)n_rows, (int)D + 1, (int)D);
+        h.A = static_cast<const float*>(z_all) + row_offset * D; h.B = m2z; h.C = pmat;
+        TVAE_PROPAGATE(gemm_launch(h, s));
+    }
+
     MmdArgs a;
     a.cols[0] = (const float*)zp; a.cols[1] = (const float*)yp; a.cnorm[0] = zn; a.cnorm[1] = yn;
     a.cols_lo[0] = a.cols_lo[1] = nullptr;
     a.split_amax = split_amax;
+    a.qflag = qflag ? &qflag->on : nullptr;
     if (p.split) {
         a.cols_lo[0] = reinterpret_cast<const float*>(static_cast<const bf16*>(zp) + lo_off);
         a.cols_lo[1] = reinterpret_cast<const float*>(static_cast<const bf16*>(yp) + lo_off);
@@ -1221,6 +1371,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     f.d_z = d_z;
     f.split_amax = split_amax;
     f.zn = zn; f.yn = yn; f.n_total = (int)n_total; f.dots = dots; f.ndots = ndots;
+    f.qflag = qflag; f.m3 = m3; f.P = pmat; f.ldP = p.ldq;
     long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
     if (fb > 4096) fb = 4096;
     if (fb < 1) fb = 1;

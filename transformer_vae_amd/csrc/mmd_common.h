@@ -11,6 +11,7 @@ struct MmdArgs {
     const float* cols[2];    // padded fp32 copies: [0] = z_all, [1] = y_all, row stride DPAD
     const float* cols_lo[2]; // split-bf16 kernels: the lo copies (cols[] are then the hi copies); else unused
     const unsigned* split_amax;   // split kernels: bits of max |value| over both sets (see split_scales)
+    const unsigned* qflag;        // split pipelined gradient launch, nullable: non-zero = accumulate Q = E + t (one gradient product; mmd.hip, QFlag)
     const float* cnorm[2];   // squared norms (0 for padding rows)
     int n_rows, n_cols, row_offset;
     int row_blocks, col_splits, tiles_per_set, n_rows_pad;

@@ -74,8 +74,16 @@ struct PipeLds {
 
 template <int V> using ic = std::integral_constant<int, V>;
 
-template <int KB, bool SPLIT>
+// QF (split only): the Q-form instance. The device-side switch QFlag (mmd.hip) selects ONE of the two instances of a
+// launch pair; the other returns at once. A runtime branch around the extra gradient products instead cost 50 registers
+// and spilled at KB >= 5.
+template <int KB, bool SPLIT, bool QF = false>
 __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
+    static_assert(SPLIT || !QF, "Q-form is a split-mode variant");
+    if constexpr (SPLIT) {
+        if (a.qflag != nullptr && (__builtin_amdgcn_readfirstlane((int)*a.qflag) != 0) != QF) return;
+    }
+    constexpr bool qform = QF;
     using L = PipeLds<KB, SPLIT>;
     constexpr int P = L::P, PT = L::PT, RT = L::RT, TPW = L::TPW, SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;
     constexpr int NE = 4 * TPW;                               // E values per lane and step
@@ -347,11 +355,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
                     ev = ok ? (big ? ex : ev) : 0.f;
                     qv = ok ? (big ? ex + tt[el] : qv) : 0.f;
                 }
-#ifdef TVAE_QFORM_PROTO      // experiment (DESIGN 9, Q-form gradient): gradient and row sums carry Q = E + t, one product
-                e[j][r] = qv;
-#else
-                e[j][r] = ev;
-#endif
+                e[j][r] = qform ? qv : ev;      // Q-form (mmd.hip, QFlag): gradient and row sums carry Q = E + t
                 q[j][r] = qv;
             }
             if (s != FIN) return;
@@ -376,15 +380,16 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const float es = e[j][r] * SPLIT_E_SCALE;
                         p0v[r] = (_Float16)es;
-                        p1v[r] = (_Float16)(es - (float)p0v[r]);
+                        if constexpr (!qform) p1v[r] = (_Float16)(es - (float)p0v[r]);
                     }
-                    uint2 b0 = __builtin_bit_cast(uint2, p0v), b1 = __builtin_bit_cast(uint2, p1v);
+                    uint2 b0 = __builtin_bit_cast(uint2, p0v), b1 = {0u, 0u};
+                    if constexpr (!qform) b1 = __builtin_bit_cast(uint2, p1v);
                     b0.x ^= flip; b0.y ^= flip; b1.x ^= flip; b1.y ^= flip;
                     // [piece][row][16 points], the two 16-byte halves of a row swapped on rows 8 .. 15 of a tile (bank
                     // spread of the consumer's reads): this lane holds points 4 g .. 4 g + 3 of row 16 (my_t0 + j) + i16
                     const int at = ((my_t0 + j) * 16 + i16) * 32 + 16 * ((g >> 1) ^ ((i16 >> 3) & 1)) + 8 * (g & 1);
                     *reinterpret_cast<uint2*>(eb + at) = b0;
-                    *reinterpret_cast<uint2*>(eb + L::EPIECE_B + at) = b1;
+                    if constexpr (!qform) *reinterpret_cast<uint2*>(eb + L::EPIECE_B + at) = b1;
                 } else {
                     b16x4_t ev;
 #pragma unroll
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 gh[blk][h] = tr_read(at + tr_off[h]);
-                gl[blk][h] = tr_read(at + 1024 + tr_off[h]);
+                if constexpr (!qform) gl[blk][h] = tr_read(at + 1024 + tr_off[h]);
             }
         } else {
             const int at = xb0 + 2048 * (blk >> 1);
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
                 const int n = lane & 31;
                 const int at = (32 * rbk + n) * 32 + 16 * ((lane >> 5) ^ ((n >> 3) & 1));
                 Bh[rbk] = *reinterpret_cast<const h16x8_t*>(eb + at);
-                Bl[rbk] = *reinterpret_cast<const h16x8_t*>(eb + L::EPIECE_B + at);
+                if constexpr (!qform) Bl[rbk] = *reinterpret_cast<const h16x8_t*>(eb + L::EPIECE_B + at);
             }
         } else {
 #pragma unroll
@@ -480,21 +485,21 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
             if (blk + TD < GB) grad_rd(xb0, blk + TD);
             if constexpr (SPLIT) {
                 const f16x8_t Ah = __builtin_bit_cast(f16x8_t, __builtin_shufflevector(gh[blk][0], gh[blk][1], 0, 1, 2, 3, 4, 5, 6, 7));
-                const f16x8_t Al = __builtin_bit_cast(f16x8_t, __builtin_shufflevector(gl[blk][0], gl[blk][1], 0, 1, 2, 3, 4, 5, 6, 7));
                 // X_hi E_hi + X_lo E_hi + X_hi E_lo, the two row blocks alternating
 #pragma unroll
                 for (int rbk = 0; rbk < 2; ++rbk)
                     acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
-#if TVAE_GRAD_PRODUCTS == 3 && !defined(TVAE_QFORM_PROTO)
+                if constexpr (!qform) {          // Q is ~1e-3 of E: its sums need one product
+                    const f16x8_t Al = __builtin_bit_cast(f16x8_t, __builtin_shufflevector(gl[blk][0], gl[blk][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#if TVAE_GRAD_PRODUCTS == 3
 #pragma unroll
-                for (int rbk = 0; rbk < 2; ++rbk)
-                    acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
+                    for (int rbk = 0; rbk < 2; ++rbk)
+                        acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8_t, Bh[rbk]), acc[blk][rbk], 0, 0, 0);
 #endif
-#ifndef TVAE_QFORM_PROTO
 #pragma unroll
-                for (int rbk = 0; rbk < 2; ++rbk)
-                    acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bl[rbk]), acc[blk][rbk], 0, 0, 0);
-#endif
+                    for (int rbk = 0; rbk < 2; ++rbk)
+                        acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8_t, Bl[rbk]), acc[blk][rbk], 0, 0, 0);
+                }
             } else {
                 const h16x8_t A1 = __builtin_bit_cast(h16x8_t, __builtin_shufflevector(gh[blk][0], gh[blk][1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
@@ -983,6 +988,17 @@ int launch_pipe(const MmdArgs& a, int nblocks, hipStream_t s) {
     }));
     hipLaunchKernelGGL((mmd_pipe_kernel<KB, SPLIT>), dim3(nblocks), dim3(256), lds_bytes, s, a);
     TVAE_CHECK_HIP(hipGetLastError());
+    if constexpr (SPLIT) {
+        if (a.qflag != nullptr) {          // the pair: exactly one of the two does the work (QFlag)
+            static PerDeviceOnce once_q;
+            TVAE_CHECK_HIP(per_device_once(once_q, [] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_pipe_kernel<KB, SPLIT, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            }));
+            hipLaunchKernelGGL((mmd_pipe_kernel<KB, SPLIT, true>), dim3(nblocks), dim3(256), lds_bytes, s, a);
+            TVAE_CHECK_HIP(hipGetLastError());
+        }
+    }
     return TVAE_OK;
 }
 
