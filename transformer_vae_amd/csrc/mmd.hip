@@ -909,7 +909,7 @@ constexpr bool kPipeSumBf16 = TVAE_PIPE_SUM_BF16 != 0;   // bf16 mode: sum-only 
 #ifndef TVAE_QFORM
 #define TVAE_QFORM 1
 #endif
-constexpr bool kQForm = TVAE_QFORM != 0;        // Q-form gradient on the split pipelined path (0: E-form, three gradient products)
+constexpr bool kQForm = TVAE_QFORM != 0 && TVAE_GRAM_PRODUCTS == 2;        // Q-form gradient on the split pipelined path (0: E-form, three gradient products)
 constexpr int kPipeMaxKb = TVAE_PIPE_MAX_KB;    // pipelined gradient kernel up to this many feature blocks per wave (0: off)
 const Shape* pick_shape(int64_t D) {
     for (const Shape& sh : kShapes)

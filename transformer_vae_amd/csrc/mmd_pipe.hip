@@ -87,7 +87,10 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     using L = PipeLds<KB, SPLIT>;
     constexpr int P = L::P, PT = L::PT, RT = L::RT, TPW = L::TPW, SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;
     constexpr int NE = 4 * TPW;                               // E values per lane and step
-    constexpr int DPS = 2;                                    // DMA instructions per 32-feature block
+    // DMA instructions per 32-feature block. Q-form: nothing reads the lo image of the column tiles (the Gram takes the
+    // column side hi-only, the one gradient product is X_hi Q_hi), so it is not fetched
+    constexpr int DPS = QF ? 1 : 2;
+    static_assert(!QF || TVAE_GRAM_PRODUCTS == 2, "the Q-form instance does not fetch the lo image the third Gram product reads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -226,7 +229,8 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     };
     // features [32 s, 32 s + 32) of the step into buffer b: two DMA instructions under one M0
     auto dma_block = [&](const Src& X, int b, int s) {
-        dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, dma_voff_b, smem_byte + xbuf_byte(b) + 2048u * s);
+        if constexpr (QF) dma16(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, smem_byte + xbuf_byte(b) + 2048u * s);
+        else dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff, dma_voff_b, smem_byte + xbuf_byte(b) + 2048u * s);
     };
 
 #ifdef TVAE_PHASE_TIMING
