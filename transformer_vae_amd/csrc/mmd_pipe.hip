@@ -54,8 +54,8 @@ struct PipeLds {
     // (bf16: the step's two point tiles; split: the hi image and the lo image of its one point tile)
     static constexpr int SLICE_B = KB * 2048;
     static constexpr int XBUF_B = 4 * SLICE_B;                // one point-tile buffer (four wave slices)
-    static constexpr int NORM_OFF = 2 * XBUF_B;               // [2 buf][4 waves][64] float point norms (P used; the DMA moves 64)
-    static constexpr int XCH_OFF = NORM_OFF + 2 * 4 * 64 * 4;
+    static constexpr int NORM_OFF = 2 * XBUF_B;               // [4 buf][4 waves][64] float point norms (P used; the DMA moves 64)
+    static constexpr int XCH_OFF = NORM_OFF + 4 * 4 * 64 * 4; // (two buffers in use, four in the Q-form instance's ring)
     static constexpr int XCH_ONE_B = NT * 3 * 64 * 16;        // [tile][3 remote sources][64 lanes] float4
     static constexpr int EBUF_OFF = XCH_OFF + 2 * XCH_ONE_B;
     static constexpr int EPIECE_B = SPLIT ? 64 * 32 : RT * 64 * 16;        // SPLIT: [row][16 points]; else [t][lane][2 pt][4]
@@ -67,6 +67,9 @@ struct PipeLds {
 
 #ifndef TVAE_PIPE_TD
 #define TVAE_PIPE_TD 2
+#endif
+#ifndef TVAE_PIPE_TD_QF
+#define TVAE_PIPE_TD_QF 2
 #endif
 #ifndef TVAE_PIPE_GD
 #define TVAE_PIPE_GD 1
@@ -221,7 +224,15 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(p0) * (unsigned)DPAD;   // the plan keeps n_pad * DPAD < 2^31
         return Src{(set ? cbase1 : cbase0) + off, (set ? nbase1 : nbase0) + p0, set, p0};
     };
-    auto xbuf_byte = [&](int b) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
+    // Q-form: the lo pieces are free (DPS above), so the same memory holds FOUR hi-only tiles, tile v in slot v & 3 = piece
+    // (v & 1) of buffer (v >> 1) & 1.  Tile k + 3 is fetched during interval k and first read in interval k + 2: a whole
+    // interval more for the L2 / Infinity Cache round trip than the in-place refill of the two-buffer scheme leaves
+    // (measured with every step fetching the same tile: the refill latency was 8 % of the kernel).
+    constexpr bool RING = QF;
+    auto xbuf_byte = [&](int b) -> unsigned {
+        if constexpr (RING) return (unsigned)(((b >> 1) & 1) * L::XBUF_B + wave * L::SLICE_B + (b & 1) * 1024);
+        else return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B);
+    };
     auto stage_norms = [&](const Src& X, int nbuf) {
         // all 64 lanes move a float (no lane mask, no branch): the words past the step's P norms are never read
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(L::NORM_OFF + (nbuf * 4 + wave) * 64 * 4));
@@ -255,9 +266,9 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     // row i16 of row tile my_t0 + j) and whether any lane leaves the polynomial's range
     float tt[NE];
     bool t_big = false;
-    auto xch_reduce = [&](int xbuf, int nbuf) {
+    f32x4 part[TPW][3], cn;
+    auto xch_fetch = [&](int xbuf, int nbuf) {
         const f32x4* xb = reinterpret_cast<const f32x4*>(sm + L::XCH_OFF + xbuf * L::XCH_ONE_B);
-        f32x4 part[TPW][3];
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
 #pragma unroll
@@ -268,7 +279,9 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
                 part[j][w] = xb[((wave * TPW + j) * 3 + w) * 64 + lane];     // all reads in flight
 #endif
             }
-        const f32x4 cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + ((nbuf * 4 + wave) * 64 + 16 * my_pt + 4 * g) * 4);
+        cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + ((nbuf * 4 + wave) * 64 + 16 * my_pt + 4 * g) * 4);
+    };
+    auto xch_finish = [&]() {
         float tm = 0.f;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {        // own partial (rotated order: still in registers) + the three others, fixed order
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         }
         t_big = __any(tm >= EM1_POLY_MAX);
     };
+    auto xch_reduce = [&](int xbuf, int nbuf) { xch_fetch(xbuf, nbuf); xch_finish(); };
 
     double sum0 = 0.0, sum1 = 0.0, rowsum[TPW];     // per-lane fp64 partials of the Q sums (by column set) and the row sums
 #pragma unroll
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     h16x8_t nab[PT], nal[SPLIT ? PT : 1];
     auto gram_prefetch = [&](int b) {
         const char* xs = sm + xbuf_byte(b);
-        wait_vmcnt_n(DPS * (KB - 1));
+        wait_vmcnt_n(DPS * (KB - 1) + (RING ? 1 + DPS * KB : 0));      // ring: the norms and blocks of the tile after it
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             if constexpr (SPLIT) {
@@ -443,7 +457,10 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     // grad_fetch issues the first operand reads (in program order ahead of the exchange reads, so that the matrix
     // instructions of block 0 can start while the next tile's partials are still being summed); grad_run does the rest.
     constexpr int GB = SPLIT ? KB : NI;                       // feature blocks of the gradient (32 / 16 features)
-    constexpr int TD = GB < TVAE_PIPE_TD ? GB : TVAE_PIPE_TD; // transposed operand reads run TD blocks ahead
+    // transposed operand reads run TD blocks ahead (Q-form: two matrix instructions per block instead of six, so the same
+    // LDS latency needs more blocks of cover)
+    constexpr int TDW = QF ? TVAE_PIPE_TD_QF : TVAE_PIPE_TD;
+    constexpr int TD = GB < TDW ? GB : TDW;
     h16x8_t Bh[SPLIT ? 2 : RT], Bl[SPLIT ? 2 : 1];
     s16x4_t gh[GB][2], gl[SPLIT ? GB : 1][2];
     auto grad_rd = [&](int xb0, int blk) {
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     };
     auto grad_fetch_x = [&](int b) {          // wave-private tile data: legal ahead of the barrier
 #pragma unroll
-        for (int blk = 0; blk < TD; ++blk) grad_rd((int)xbuf_byte(b), blk);
+        for (int blk = 0; blk < TD && blk < GB; ++blk) grad_rd((int)xbuf_byte(b), blk);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto grad_fetch_e = [&](int ebuf) {
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto grad_run = [&](int b, const Src& Xn) {
+    auto grad_run = [&](int b, int fill, const Src& Xn) {
         const int xb0 = (int)xbuf_byte(b);
 #pragma unroll
         for (int blk = 0; blk < GB; ++blk) {
@@ -512,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
             if (SPLIT || (blk & 1)) {
                 // the MFMAs of the 32-feature block are issued (their operand reads have completed) before the refill
                 __builtin_amdgcn_sched_barrier(0);
-                dma_block(Xn, b, SPLIT ? blk : blk >> 1);
+                dma_block(Xn, fill, SPLIT ? blk : blk >> 1);
             }
         }
     };
@@ -527,16 +544,19 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 #else
         const int cur = k & 1, nxt = cur ^ 1;
 #endif
+        // point-tile slots: this tile's, the next one's (Gram), the one to fill; norm buffers go with the slots
+        const int xs_cur = RING ? (k & 3) : cur, xs_nxt = RING ? ((k + 1) & 3) : nxt, xs_fill = RING ? ((k + 3) & 3) : cur;
+        constexpr int FSLACK = RING ? 1 + DPS * KB : 0;
         // this interval's scalars (c_set, c_p0, slow, Xn2) were worked out at the end of the previous one, behind its
         // last matrix instructions, instead of at the top of this one with the matrix pipe idle
         const Src Xn2 = Xn2_c;
         const int c_set = c_set_c, c_p0 = c_p0_c;
         // Gram of the next tile  ||  E of this one (from tt, left by the previous interval)
         PHASE_MARK(5);
-        if (slow_c) front(std::true_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);   // wave-uniform
-        else front(std::false_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);
+        if (slow_c) front(std::true_type{}, std::true_type{}, xs_nxt, FSLACK, c_set, c_p0, cur);   // wave-uniform
+        else front(std::false_type{}, std::true_type{}, xs_nxt, FSLACK, c_set, c_p0, cur);
         PHASE_MARK(0);
-        grad_fetch_x(cur);          // in flight while the last matrix instructions of the Gram drain
+        grad_fetch_x(xs_cur);       // in flight while the last matrix instructions of the Gram drain
 #ifndef TVAE_DEBUG_NO_XCH
         xch_write(nxt);
 #endif
@@ -549,14 +569,18 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         PHASE_MARK(2);
         // gradient of this tile (+ refill with tile k + 2)  ||  reduce of the next tile's partials
         grad_fetch_e(cur);
-        stage_norms(Xn2, cur);
-        xch_reduce(nxt, nxt);
+        stage_norms(Xn2, xs_fill);
+        // the partials' LDS round trip and the sums run behind the gradient's matrix instructions
+        xch_fetch(nxt, xs_nxt);
+        __builtin_amdgcn_sched_barrier(0);
         PHASE_MARK(3);
-        grad_run(cur, Xn2);
+        grad_run(xs_cur, xs_fill, Xn2);
+        xch_finish();
         step_meta(sb + k + 1, c_set_c, c_p0_c);
-        Xn2_c = step_src(sb + k + 3);
+        Xn2_c = step_src(sb + k + (RING ? 4 : 3));
         slow_c = any_invalid || t_big || c_p0_c + P > a.n_cols;
-        gram_prefetch(cur);         // the next interval's Gram runs on the tile just refilled into this buffer
+        // the next interval's Gram: the tile just refilled into this buffer, or (ring) the slot after the next
+        gram_prefetch(RING ? ((k + 2) & 3) : cur);
         PHASE_MARK(4);
     };
 
@@ -570,7 +594,13 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
             stage_norms(X1, 1);
 #pragma unroll
             for (int s = 0; s < KB; ++s) dma_block(X1, 1, s);
-            front(std::false_type{}, std::false_type{}, 0, 1 + DPS * KB, 0, 0, 0);
+            if constexpr (RING) {
+                const Src X2 = step_src(sb + 2);
+                stage_norms(X2, 2);
+#pragma unroll
+                for (int s = 0; s < KB; ++s) dma_block(X2, 2, s);
+            }
+            front(std::false_type{}, std::false_type{}, 0, (RING ? 2 : 1) * (1 + DPS * KB), 0, 0, 0);
             xch_write(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -578,7 +608,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
             xch_reduce(0, 0);
             gram_prefetch(1);
             step_meta(sb, c_set_c, c_p0_c);
-            Xn2_c = step_src(sb + 2);
+            Xn2_c = step_src(sb + (RING ? 3 : 2));
             slow_c = any_invalid || t_big || c_p0_c + P > a.n_cols;
         }
 #ifdef TVAE_PIPE_UNROLL2
