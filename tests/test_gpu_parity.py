@@ -817,6 +817,28 @@ def test_mmd_far_apart_and_coincident_points(N, D, scale, dtype):
         assert float(zt.grad.abs().max()) <= 1e-6 * max(np.abs(gref).max(), 1e-12) + 1e-12
 
 
+@pytest.mark.parametrize("scale", [0.5, 1.5, 1.9, 2.1, 2.6, 6.0])
+@pytest.mark.parametrize("N,D,shift", [(1500, 256, 0.0), (700, 768, 0.6)])
+def test_mmd_qform_switch_both_sides(N, D, shift, scale):
+    """The pipelined split path (192 < D <= 768) carries Q = E + t in its gradient sums, with the linear part in closed
+    form, when 4 max|x|^2 / D^2 < 1/16 over all points, and E itself otherwise (a switch worked out on the device,
+    mmd.hip QFlag).  Priors scaled to either side of that bound, and latents with a non-zero mean (the closed form's
+    moments are then large against the kernel part): the same tolerance holds on both sides."""
+    from transformer_vae_amd import functional as F
+    rs = np.random.RandomState(int(N + D + 10 * scale))
+    z = (np.tanh(rs.standard_normal((N, D))) + shift).astype(np.float32)
+    y = (rs.standard_normal((N, D)) * scale).astype(np.float32)
+    zt = torch.from_numpy(z).to(dev()).requires_grad_(True)
+    yt = torch.from_numpy(y).to(dev())
+    reg = F.mmd_reg_loss(zt, yt, batch_size=1, n_latents=1)
+    reg.backward()
+    z64, y64 = z.astype(np.float64), y.astype(np.float64)
+    ref = orc.mmd_gram(y64, z64)
+    gref = orc.mmd_grad_latent_rows(z64, z64, y64)
+    assert abs(float(reg.detach()) - ref) <= F32_TOL * abs(ref), (float(reg.detach()), ref)
+    assert relerr(zt.grad.cpu().numpy(), gref) <= F32_TOL
+
+
 @pytest.mark.parametrize("N,D", [(1024, 77), (512, 768), (300, 33)])
 def test_mmd_all_zero_inputs(N, D):
     """Latents and priors all zero (the split modes' max |value| is 0: the scale falls back to 2^12): every kernel
