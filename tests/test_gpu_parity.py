@@ -792,7 +792,7 @@ def test_mmd_tiny_sample_counts(N, D):
 
 @pytest.mark.parametrize("N,D,scale,dtype", [(300, 5, 8.0, torch.float32), (700, 77, 12.0, torch.float32),
                                              (9000, 40, 6.0, torch.float32), (600, 768, 30.0, torch.float32),
-                                             (600, 768, 30.0, torch.bfloat16), (200, 1100, 40.0, torch.float32),
+                                             (600, 768, 30.0, torch.bfloat16), (200, 1100, 40.0, torch.float32), (500, 900, 40.0, torch.float32),
                                              (256, 64, 0.0, torch.float32), (1280, 77, 0.0, torch.float32),
                                              (1100, 40, 25.0, torch.float32), (640, 512, 0.0, torch.float32)])
 def test_mmd_far_apart_and_coincident_points(N, D, scale, dtype):
@@ -818,9 +818,9 @@ def test_mmd_far_apart_and_coincident_points(N, D, scale, dtype):
 
 
 @pytest.mark.parametrize("scale", [0.5, 1.5, 1.9, 2.1, 2.6, 6.0])
-@pytest.mark.parametrize("N,D,shift", [(1500, 256, 0.0), (700, 768, 0.6)])
+@pytest.mark.parametrize("N,D,shift", [(1500, 256, 0.0), (700, 768, 0.6), (600, 1000, 0.3), (520, 1024, 0.0)])
 def test_mmd_qform_switch_both_sides(N, D, shift, scale):
-    """The pipelined split path (192 < D <= 768) carries Q = E + t in its gradient sums, with the linear part in closed
+    """The split kernels of 192 < D <= 1024 (pipelined up to 768, 32-row kernels beyond) carry Q = E + t in its gradient sums, with the linear part in closed
     form, when 4 max|x|^2 / D^2 < 1/16 over all points, and E itself otherwise (a switch worked out on the device,
     mmd.hip QFlag).  Priors scaled to either side of that bound, and latents with a non-zero mean (the closed form's
     moments are then large against the kernel part): the same tolerance holds on both sides."""

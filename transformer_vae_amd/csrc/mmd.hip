@@ -1060,7 +1060,8 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
 #endif
     p->off_sync = take((int64_t)p->sync_groups * 8 * p->sync_epochs * 4);
     p->off_amax = take(p->split ? 256 + AMAX_BLOCKS * 4 : 0);      // the scale word, then the per-block maxima
-    p->qform = (kQForm && p->pipe && p->split && want_grad) ? 1 : 0;
+    // Q-form gradient: the split pipelined kernels, and the split 32-row kernels of 768 < D <= 1024
+    p->qform = (kQForm && p->split && want_grad && !p->n16 && (p->pipe || (bf16_tiles && p->NB >= 7 && p->RT == 2))) ? 1 : 0;
     p->ldq = (int)align_up(D + 1, 4);
     p->off_col3 = take(p->qform ? (int64_t)2 * p->nwaves * p->DPAD * 4 : 0);
     p->off_m3 = take(p->qform ? (int64_t)p->DPAD * 4 : 0);

@@ -80,13 +80,20 @@ struct Bf16Lds {
 // by the matrix cores; the dropped lo x lo terms are 2^-22 of a product.  A first version on bf16 halves (16 bits)
 // failed the 1e-5 bar on the gradient when the kernel values are O(1) (far-apart points: 1.003e-5).  Everything else
 // (norms, t, expm1, sums, row sums) is the fp32 / fp64 arithmetic of the exact kernel; the scale is undone exactly.
-template <int KB, int RT, bool GRAD, bool SPLIT>
+// QF (split gradient launches): the Q-form instance of mmd_pipe.hip / DESIGN 4.1g -- gradient and row sums carry
+// Q = E + t in ONE fp16 product, the lo images of columns and E are neither fetched nor formed.  A launch pair; the
+// device-side flag picks the instance that runs.
+template <int KB, int RT, bool GRAD, bool SPLIT, bool QF = false>
 __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
+    static_assert(!QF || (GRAD && SPLIT && TVAE_GRAM_PRODUCTS == 2), "Q-form: split gradient launches with the two-product Gram");
+    if constexpr (GRAD && SPLIT) {
+        if (a.qflag != nullptr && (__builtin_amdgcn_readfirstlane((int)*a.qflag) != 0) != QF) return;
+    }
     using L = Bf16Lds<KB, RT, GRAD, SPLIT>;
     static_assert(GRAD || RT == 2, "the symmetric y-y enumeration assumes 32-row blocks");
     constexpr int SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;     // NI: 16-feature blocks per slice
     // (with the two-product Gram of mmd_common.h a sum-only launch never reads the lo copy of the columns)
-    constexpr bool NEED_LO = SPLIT && (GRAD || TVAE_GRAM_PRODUCTS == 3);
+    constexpr bool NEED_LO = SPLIT && ((GRAD && !QF) || TVAE_GRAM_PRODUCTS == 3);
     constexpr int DPS = NEED_LO ? 4 : 2;                      // DMA instructions per 32-feature block pair
     constexpr int TPW = L::TPW, ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -381,7 +388,11 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
                     for (int j = 0; j < TPW; ++j) { e[j][r] = 0.f; q[j][r] = 0.f; }
                 }
         }
-        // sums carry Q (linear part: closed form in the finalize kernel); row sums carry E
+        // sums carry Q (linear part: closed form in the finalize kernel); row sums carry E (Q-form: Q as well)
+        if constexpr (QF) {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) e[j] = q[j];
+        }
         float qs_all = 0.f;
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
@@ -413,13 +424,16 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
                     for (int r = 0; r < 4; ++r) {
                         const float es = e[j][r] * SPLIT_E_SCALE;
                         eh[r] = (_Float16)es;
-                        el[r] = (_Float16)(es - (float)eh[r]);
+                        if constexpr (!QF) el[r] = (_Float16)(es - (float)eh[r]);
                     }
-                    uint2 hbits = __builtin_bit_cast(uint2, eh), lbits = __builtin_bit_cast(uint2, el);
+                    uint2 hbits = __builtin_bit_cast(uint2, eh);
                     hbits.x ^= flip; hbits.y ^= flip;
-                    lbits.x ^= flip; lbits.y ^= flip;
                     ebuf[((my_t0 + j) * 64 + lane) * 2 + my_pt] = hbits;
-                    ebuf[(L::EBUF_ONE_B / 8) + ((my_t0 + j) * 64 + lane) * 2 + my_pt] = lbits;
+                    if constexpr (!QF) {
+                        uint2 lbits = __builtin_bit_cast(uint2, el);
+                        lbits.x ^= flip; lbits.y ^= flip;
+                        ebuf[(L::EBUF_ONE_B / 8) + ((my_t0 + j) * 64 + lane) * 2 + my_pt] = lbits;
+                    }
                 } else {
                     bf16x4_t eb;
 #pragma unroll
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 Eb[t] = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + (t * 64 + lane) * 16);
-                if constexpr (SPLIT) El[t] = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + L::EBUF_ONE_B + (t * 64 + lane) * 16);
+                if constexpr (SPLIT && !QF) El[t] = *reinterpret_cast<const bf16x8_t*>(sm + L::EBUF_B + L::EBUF_ONE_B + (t * 64 + lane) * 16);
             }
             const int tb0 = wave * L::SLICE_W + tr_off0, tb1 = wave * L::SLICE_W + tr_off1;
             // transposed operand reads run TD blocks ahead of their MFMAs
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
                 const int nb = ((db & 1) ? tb1 : tb0) + 2048 * (db >> 1);
                 ga[db][0] = tr_read(nb);
                 ga[db][1] = tr_read(nb + 1024);
-                if constexpr (SPLIT) {
+                if constexpr (SPLIT && !QF) {
                     gl[db][0] = tr_read(nb + L::SLICE_B);
                     gl[db][1] = tr_read(nb + L::SLICE_B + 1024);
                 }
@@ -465,7 +479,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
                     acc[db][t] = mfma16<SPLIT>(ab2, Eb[t], acc[db][t]);
-                if constexpr (SPLIT) {
+                if constexpr (SPLIT && !QF) {
                     const s16x8_t lv = __builtin_shufflevector(gl[db][0], gl[db][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     const bf16x8_t al2 = __builtin_bit_cast(bf16x8_t, lv);
 #pragma unroll
@@ -553,6 +567,21 @@ int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
     const int lds_launch = lds_bytes + debug_lds_pad() > lds_attr ? lds_attr : lds_bytes + debug_lds_pad();
     hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD, SPLIT>), dim3(nblocks), dim3(256), lds_launch, s, a);
     TVAE_CHECK_HIP(hipGetLastError());
+    if constexpr (GRAD && SPLIT) {
+        if (a.qflag != nullptr) {          // the pair: exactly one of the two does the work (mmd.hip, QFlag)
+            if constexpr (RT == 2 && KB >= 7 && TVAE_GRAM_PRODUCTS == 2) {
+                static PerDeviceOnce once_q;
+                TVAE_CHECK_HIP(per_device_once(once_q, [] {
+                    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD, SPLIT, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
+                }));
+                hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD, SPLIT, true>), dim3(nblocks), dim3(256), lds_launch, s, a);
+                TVAE_CHECK_HIP(hipGetLastError());
+            } else {
+                return fail(TVAE_ERR_ARG, "mmd: no Q-form instance of the split kernel for %d feature blocks, %d row tiles", KB, RT);
+            }
+        }
+    }
     return TVAE_OK;
 }
 
