@@ -38,7 +38,10 @@ extern "C" {
  * Plain TVAE_F32 gives the MMD the same accuracy class (1e-5 of the fp32 reference on loss and gradient, fp32
  * accumulation, fp64 reductions) but, for latent_size <= 1024 (latent_size <= 192: from 1024 points on), forms each
  * fp32 product from two (Gram: row operand hi + lo, column operand hi) or three (gradient) fp16 matrix-core products of
- * scaled hi/lo halves, at several times the speed (measured error against fp64: 1e-7 .. 5e-7). */
+ * scaled hi/lo halves, at several times the speed (measured error against fp64: 1e-7 .. 5e-7).  For
+ * 192 < latent_size <= 1024 the gradient's part linear in the squared distances is closed form (moments and three small
+ * fp32 GEMMs inside the call) and the remainder takes one fp16 product; a device-side switch keeps the
+ * three-product form when the points' norms are large against latent_size. */
 #define TVAE_F32_STRICT 2
 
 #define TVAE_OK 0
