@@ -1010,9 +1010,15 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     // chunk the previous sets left in the cache (cfg4 size: 641 -> 492 ms; sweep in DESIGN 4.1b).  Costs one
     // gradient slab per split (capped at 32 GiB).
     p->sp_major = 0;
+    // Q-form gradient (DESIGN 4.1g): the split pipelined kernels, and the split 32-row kernels of 768 < D <= 1024
+    p->qform = (kQForm && p->split && want_grad && !p->n16 && (p->pipe || (bf16_tiles && p->NB >= 7 && p->RT == 2))) ? 1 : 0;
     if (bf16_tiles) {
         const int64_t col_bytes = 2ll * p->n_pad * p->DPAD * (p->split ? 4 : 2);
-        if (col_bytes > (64ll << 20)) {
+        // the pipelined Q-form instance fetches tiles three intervals ahead into its ring and no longer cares (cfg4 size,
+        // whole call: 1 split 618 ms, 4 -> 622, 16 -> 630, 40 -> 640; N = 65 536: 46.9 / 47.0 / 47.8 at 1 / 3 / 8), so it
+        // keeps the load-balance count above and one gradient slab (cfg4: 3.0 GB of workspace instead of 13.8); the
+        // rare E-form fallback of such a call runs unchunked (~15 % slower at that size)
+        if (col_bytes > (64ll << 20) && !(p->qform && p->pipe)) {
             // chunk size: ~24 MB for the one-product kernels (a step lasts ~1 us); the split kernels do two to three times the
             // matrix work per byte (~5 us per step) and are at their best with ~96 MB (cfg4 size: 1 split 1 435 ms,
             // 4 -> 1 353, 8 -> 1 252, 16 -> 1 217, 32 -> 1 225, 63 -> 1 232)
@@ -1060,8 +1066,6 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
 #endif
     p->off_sync = take((int64_t)p->sync_groups * 8 * p->sync_epochs * 4);
     p->off_amax = take(p->split ? 256 + AMAX_BLOCKS * 4 : 0);      // the scale word, then the per-block maxima
-    // Q-form gradient (DESIGN 4.1g): the split pipelined kernels, and the split 32-row kernels of 768 < D <= 1024
-    p->qform = (kQForm && p->split && want_grad && !p->n16 && (p->pipe || (bf16_tiles && p->NB >= 7 && p->RT == 2))) ? 1 : 0;
     p->ldq = (int)align_up(D + 1, 4);
     p->off_col3 = take(p->qform ? (int64_t)2 * p->nwaves * p->DPAD * 4 : 0);
     p->off_m3 = take(p->qform ? (int64_t)p->DPAD * 4 : 0);
