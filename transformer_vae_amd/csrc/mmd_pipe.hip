@@ -556,11 +556,19 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         if (slow_c) front(std::true_type{}, std::true_type{}, xs_nxt, FSLACK, c_set, c_p0, cur);   // wave-uniform
         else front(std::false_type{}, std::true_type{}, xs_nxt, FSLACK, c_set, c_p0, cur);
         PHASE_MARK(0);
-        grad_fetch_x(xs_cur);       // in flight while the last matrix instructions of the Gram drain
+        // the barrier needs the partials' WRITES retired, not the gradient's operand reads: LDS operations retire in
+        // order, so with the reads issued behind the writes a counted wait leaves them in flight across the barrier
 #ifndef TVAE_DEBUG_NO_XCH
         xch_write(nxt);
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");          // the reads below stay behind the writes (the count depends on it)
+        __builtin_amdgcn_sched_barrier(0);
+        grad_fetch_x(xs_cur);
+        {
+            constexpr int NRD = (GB < TDW ? GB : TDW) * (SPLIT ? (QF ? 2 : 4) : 2);      // grad_fetch_x's reads
+            static_assert(NRD <= 15, "lgkmcnt is a 4-bit counter");
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
+        }
         PHASE_MARK(1);
 #ifndef TVAE_DEBUG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
