@@ -130,3 +130,42 @@ def test_graph_replay_of_a_large_mmd_call(strict):
     gref = orc.mmd_grad_latent_rows(z_new.double().cpu().numpy()[rows], z_new.double().cpu().numpy(),
                                     y_new.double().cpu().numpy())
     assert relerr(z_buf.grad.cpu().numpy()[rows], gref) <= F32_TOL
+
+
+def test_graph_replay_switches_gradient_form_on_the_device():
+    """The Q-form / E-form choice of the split kernels (192 < D <= 1024) is made on the device from the inputs' norms, so
+    ONE captured graph serves both: replays alternate between ordinary priors (Q-form) and priors scaled so that
+    4 |y|^2 / D^2 passes 1/16 (E-form) and must reproduce the eager results bit for bit, and the oracle's to 1e-5."""
+    import transformer_vae_amd as amd
+    from transformer_vae_amd import functional as F
+    N, D = 4096, 512
+    gen = torch.Generator(device=dev()).manual_seed(7)
+
+    def draw(scale):
+        return (torch.tanh(torch.randn((N, D), generator=gen, device=dev())),
+                torch.randn((N, D), generator=gen, device=dev()) * scale)
+
+    z_buf, y_buf = draw(1.0)
+    z_buf.requires_grad_(True)
+
+    def step(z, y):
+        loss = F.mmd_reg_loss(z, y, batch_size=1, n_latents=1)
+        loss.backward()
+        return loss
+
+    gs = amd.GraphedStep(step, (z_buf, y_buf), zero_grads=[z_buf])
+    rows = np.arange(0, N, 97)
+    for scale in (1.0, 5.0, 1.0, 5.0):
+        z_new, y_new = draw(scale)
+        loss = gs(z_new, y_new)
+        torch.cuda.synchronize()
+        zt = z_new.clone().requires_grad_(True)
+        want = F.mmd_reg_loss(zt, y_new, batch_size=1, n_latents=1)
+        want.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(loss.detach(), want.detach())
+        assert torch.equal(z_buf.grad, zt.grad)
+        z64, y64 = z_new.double().cpu().numpy(), y_new.double().cpu().numpy()
+        ref = orc.mmd_gram(y64, z64)
+        assert abs(float(loss.detach()) - ref) <= F32_TOL * abs(ref)
+        assert relerr(z_buf.grad.cpu().numpy()[rows], orc.mmd_grad_latent_rows(z64[rows], z64, y64)) <= F32_TOL
