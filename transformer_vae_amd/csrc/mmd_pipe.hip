@@ -987,9 +987,15 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
             front(std::true_type{}, nxt, Xr, (k + 3) & 3, cur, k & 3, m);
             m = step_meta(sb + k + 1);                    // the next interval's scalars, ahead of the barrier wait
             Xr = step_src(sb + k + 4);
-            gram_prefetch(cur);                           // interval k + 1 runs its Gram on buffer cur (tile k + 2)
+            // the barrier needs the partials' writes retired, not the operand reads behind them (see mmd_pipe_kernel)
             xch_write(nxt);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            gram_prefetch(cur);                           // interval k + 1 runs its Gram on buffer cur (tile k + 2)
+            {
+                constexpr int NRD = PT * (LS ? 2 : 1);                // gram_prefetch's reads
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
