@@ -615,6 +615,39 @@ def test_mmd_narrow_split_row_blocks_compose(R, D):
     assert abs(float(loss_full.detach()) - ref) <= F32_TOL * abs(ref)
 
 
+@pytest.mark.parametrize("N,D,block", [(4672, 31, 1280), (4672, 77, 1280), (2144, 150, 640), (1184, 192, 1024)])
+def test_mmd_narrow_split_whole_block_rows_of_a_padded_point_set(N, D, block):
+    """mmd_n16.hip compiles its edge masks out when the host sees none to apply.  A row block of whole 128-row workgroups
+    out of a point count that is a multiple of 32 but not of the 128-point padding unit has no ragged row and no ragged
+    32-point step, yet the walk covers padding points behind the last column (found by tools/fuzz_gpu.py seed 4242: the
+    sums were off by 4e-5 with the gradient still right, because the padding's z-z and z-y terms cancel in the row
+    sums).  Per shard: z-z and z-y sums and the gradient against the oracle; over all shards: the y-y total (aligned
+    shards walk the y-y pairs symmetrically, so only their total is the oracle's)."""
+    from transformer_vae_amd import functional as F
+    rs = np.random.RandomState(N + D)
+    z = np.tanh(rs.standard_normal((N, D))).astype(np.float32)
+    y = rs.standard_normal((N, D)).astype(np.float32)
+    zt, yt = torch.from_numpy(z).to(dev()), torch.from_numpy(y).to(dev())
+    z64, y64 = z.astype(np.float64), y.astype(np.float64)
+    ls, gs = F.mmd_scales(7, 3, N, D)
+    tot = np.zeros(3)
+    for lo in range(0, N, block):
+        hi = min(N, lo + block)
+        rows = zt[lo:hi].clone().requires_grad_(True)
+        loss, sums = F.mmd_row_block(rows, zt, yt, lo, ls, gs)
+        loss.backward()
+        got = sums.cpu().numpy()
+        tot += got
+        ref = orc.mmd_partial_sums(z64[lo:hi], y64[lo:hi], z64, y64)
+        for g, r in zip(got[:2], ref[:2]):
+            assert abs(g - r) <= 1e-6 * abs(r) + 1e-9, (lo, hi, got, ref)
+        gref = orc.mmd_grad_latent_rows(z64[lo:hi], z64, y64) * (3.0 / 7.0)
+        assert relerr(rows.grad.cpu().numpy(), gref) <= F32_TOL
+    ref = orc.mmd_partial_sums(z64, y64, z64, y64)
+    for g, r in zip(tot, ref):
+        assert abs(g - r) <= 1e-6 * abs(r) + 1e-9, (tot, ref)
+
+
 def _mmd_fp64_on_gpu(z, y, chunk=4096):
     """Chunked fp64 evaluation of the MMD on the GPU (torch): the ground truth at sizes the CPU oracle cannot reach."""
     D = z.shape[1]

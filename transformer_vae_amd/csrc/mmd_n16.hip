@@ -409,7 +409,9 @@ void launch_n16_inst(const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
 
 template <int KBN, int RT>
 int launch_n16(bool grad, const MmdArgs& a, int nwg0, int nwg1, hipStream_t s) {
-    const bool edge = a.n_rows % (N16_WAVES * 16 * RT) != 0 || a.n_cols % (N16_PT * TILE_P) != 0;
+    // no partial row block, and no padding points behind the last column (the walk covers the PADDED sets: a row block of
+    // whole workgroups out of a point count that is not a multiple of the padding unit still needs the masks)
+    const bool edge = a.n_rows % (N16_WAVES * 16 * RT) != 0 || a.n_cols != a.tiles_per_set * TILE_P;
     if (grad) { if (edge) launch_n16_inst<KBN, RT, true, true>(a, nwg0, nwg1, s); else launch_n16_inst<KBN, RT, true, false>(a, nwg0, nwg1, s); }
     else { if (edge) launch_n16_inst<KBN, RT, false, true>(a, nwg0, nwg1, s); else launch_n16_inst<KBN, RT, false, false>(a, nwg0, nwg1, s); }
     TVAE_CHECK_HIP(hipGetLastError());
