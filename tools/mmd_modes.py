@@ -24,7 +24,7 @@ CODES = {"split": 0, "bf16": 1, "strict": 2}
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 z = torch.tanh(torch.randn((N, D), generator=g, device=dev) + float(os.environ.get("TVAE_MODES_SHIFT", "0")))   # shift: latents with a non-zero mean
-y = torch.randn((N, D), generator=g, device=dev)
+y = torch.randn((N, D), generator=g, device=dev) * float(os.environ.get("TVAE_MODES_YSCALE", "1"))   # > ~2.2 at D = 768: the E-form fallback of the Q-form calls
 lib = _lib.lib()
 ls, gs = 1.0 / float(N) ** 2, 4.0 / (float(N) ** 2 * float(D) ** 2)
 
