@@ -118,13 +118,13 @@ def mmd_roofline(mode, L, achieved, kern_ms, launches, traffic=None):
                          "algorithmic flops (the symmetric y-y launch executes half of its share)"}
 
 
-def make_vae(d, L, n, device, dtype, scope, world, mmd_dtype=None, strict=False):
+def make_vae(d, L, n, device, dtype, scope, world, mmd_dtype=None, strict=False, compensate=False):
     import transformer_vae_amd as amd
     cfg = SimpleNamespace(t5=SimpleNamespace(d_model=d), funnel=SimpleNamespace(d_model=d, layer_norm_eps=1e-9),
                           latent_size=L, n_latent_tokens=n)
     torch.manual_seed(0)      # default nn.Linear / LayerNorm init under seed 0
     vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](cfg), amd.VAE_DECODER_MODELS[""](cfg), True,
-                                mmd_scope=scope, compensate_ddp_mean=False, mmd_dtype=mmd_dtype, mmd_strict_fp32=strict)
+                                mmd_scope=scope, compensate_ddp_mean=compensate, mmd_dtype=mmd_dtype, mmd_strict_fp32=strict)
     return vae.to(device).to(dtype)
 
 
@@ -190,7 +190,7 @@ def cpu_baseline(cfg_name, world):
                       f"(sums + gradient) and {bs} of {B} sequences through the projections, scaled to the full step"}
 
 
-def side_config(cfg_name, device, graphed):
+def side_config(cfg_name, device, graphed, lib=None):
     """A bounded run of one of the small BASELINE configs on this GPU (rank 0, N=1 only): the headline stays
     on the default workload, these ride along in `other_configs`.  `graphed`: the whole step (forward, loss,
     backward) captured once into a HIP graph and replayed -- the launch-bound configs spend their time in
@@ -223,7 +223,8 @@ def side_config(cfg_name, device, graphed):
         clear()
         step(h, prior)
     torch.cuda.synchronize(device)
-    steps = 200 if cfg_name in ("cfg1", "cfg2") else 40
+    steps = 200 if cfg_name in ("cfg1", "cfg2") else (40 if cfg_name == "cfg3" else 5)
+    events = HipEvents() if (lib is not None and not graphed) else None
     if graphed:
         from transformer_vae_amd.graph import GraphedStep
         gs = GraphedStep(step, (h, prior), zero_grads=[h] + params)
@@ -231,20 +232,26 @@ def side_config(cfg_name, device, graphed):
         def run():
             return gs(h, prior)
     else:
-        def run():
+        def run(timed=False):
             clear()
+            if timed and events is not None:
+                lib.tvae_profile_next_mmd(*events.new_pair())
             return step(h, prior)
-    for _ in range(5):
+    for _ in range(5 if steps > 5 else 1):
         run()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
-        run()
+        run(True) if events is not None else run()
     torch.cuda.synchronize(device)
     sec = (time.perf_counter() - t0) / steps
     assert h.grad is not None and bool(torch.isfinite(h.grad).all())
     res = {"workload": f"{cfg_name}: {label}", "value": B / sec, "unit": "samples/s", "ms_per_step": sec * 1e3,
            "steps": steps, "hip_graph": bool(graphed)}
+    if events is not None and L > 192:
+        # MFMA-bound configuration: roofline of its MMD tile kernels, HIP events inside the timed steps (as the headline's)
+        k_ms = float(np.mean(events.durations_ms()))
+        res["roofline"] = mmd_roofline(mmd_mode(L, False, False), L, 10.0 * N * N * L / (k_ms * 1e-3) / 1e12, k_ms, steps)
     if cfg_name == "cfg3":
         # SURVEY.md 8d, algorithmic HBM bytes of one fp32 step: h[:, :n] read + dh[:, :n] written + recon written + G0 read
         # (4 N d), the zero-fill of dh[:, n:] (B (S - n) d), z written + re-read (~4 N D), the prior read twice (2 N D),
@@ -313,18 +320,22 @@ def main():
     others = None
     if rank == 0 and world == 1 and not args.no_side_configs:
         others = []
-        for name, graphed in (("cfg1", False), ("cfg1", True), ("cfg2", False), ("cfg2", True), ("cfg3", False), ("cfg3", True)):
+        for name, graphed in (("cfg1", False), ("cfg1", True), ("cfg2", False), ("cfg2", True), ("cfg3", False), ("cfg3", True),
+                              ("cfg5", False)):
             if name == args.config:
                 continue
             try:
-                others.append(side_config(name, device, graphed))
+                others.append(side_config(name, device, graphed, lib if name == "cfg5" else None))
             except Exception as e:
                 others.append({"workload": name, "hip_graph": graphed, "value": None, "error": repr(e)[:200]})
         torch.cuda.synchronize(device)
         torch.cuda.empty_cache()
     mmd_bf16 = args.mmd_dtype == "bf16"
+    # N > 1: global-batch MMD with the DDP compensation on (each rank's latent gradient x R), and the parameter gradients
+    # averaged over the ranks inside the timed step, as DistributedDataParallel does for the reference's trainer
+    # (trainer.py:258-281; HF Trainer wraps the model in DDP): ONE flat all-reduce of all six bottleneck gradients
     vae = make_vae(d, L, n, device, dtype, "global" if world > 1 else "local", world,
-                   torch.bfloat16 if mmd_bf16 else None, args.mmd_strict_fp32)
+                   torch.bfloat16 if mmd_bf16 else None, args.mmd_strict_fp32, compensate=world > 1)
     # rank r takes rows [r B/R, (r+1) B/R) of the SAME global tensors (generated on every rank from
     # the same seeds, sliced, the rest released), so reg_loss is the same number at every N -- a built-in check
     # of the sharded path against the single-GPU one.
@@ -356,6 +367,14 @@ def main():
         out = vae(input_encoding=h, true_samples=prior)
         loss = out.reg_loss * REG_W + (out.reconstructed_encoding * g0).sum()
         loss.backward()
+        if world > 1:
+            from transformer_vae_amd.distributed import all_reduce_sum
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            all_reduce_sum(flat).div_(world)
+            off = 0
+            for p in params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
         return out
 
     def fence():
@@ -410,6 +429,8 @@ def main():
                    "n_latent_tokens": n, "latent_size": L, "mmd_rows": N,
                    "parallelism": f"row-sharded global-batch MMD x{world}" if world > 1 else "single GPU"},
         "reg_loss": reg, "roofline": roofline,
+        "ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "param_grad_allreduce": world > 1,
     }
     if rank == 0 and world == 1 and others is not None and not mmd_bf16 and args.dtype == "fp32" and 192 < L <= 1024:
         # the other two arithmetic modes of the MMD on the SAME inputs, reported beside the headline, never instead of it:

@@ -20,8 +20,10 @@
  *     *_workspace_bytes() query (a host-only function);
  *   - return value: 0 on success, a TVAE_ERR_* code otherwise; tvae_last_error()
  *     returns a thread-local, human-readable message for the last failure;
- *   - no global mutable state: concurrent calls from different host threads on
- *     different streams (nn.DataParallel replicas) are safe.
+ *   - concurrent calls from different host threads on different streams (nn.DataParallel
+ *     replicas) are safe: the only state the library keeps is per-device and write-once
+ *     (kernel attribute bits, the address of tvae_mmd_fwd_bwd_static's scratch array) plus the
+ *     thread-local error message and measurement hook.
  */
 #ifndef TVAE_HIP_H
 #define TVAE_HIP_H
@@ -230,6 +232,14 @@ int tvae_upsample_bwd(const void* d_out, void* d_x, int64_t B, int64_t n, int64_
  * (fp32), or NULL to use the scalar `ratio`.  Forward only (its callers work on detached latents). */
 int tvae_slerp(const void* t1, const void* t2, const float* ratios, float ratio, void* out,
                int64_t rows, int64_t dim, int dtype, void* stream);
+
+/* The kernel matrix itself.  Replaces EncoderDecoderVAE._compute_kernel, autoencoders.py:117-126, for callers that want the
+ * (nx, ny) matrix (subclasses, notebooks):  K[i][j] = exp(-(sum_c (x[i][c] - y[j][c])^2 / D) / D), direct-difference form in
+ * fp32 like the reference.  The training path never materialises it (tvae_mmd_fwd_bwd).  x (nx, D), y (ny, D), K (nx, ny),
+ * all fp32.  Backward: gK (nx, ny) cotangent of K -> dx (nx, D), dy (ny, D), either nullable. */
+int tvae_rbf_kernel_fwd(const float* x, const float* y, int64_t nx, int64_t ny, int64_t D, float* K, void* stream);
+int tvae_rbf_kernel_bwd(const float* x, const float* y, const float* K, const float* gK, int64_t nx, int64_t ny, int64_t D,
+                        float* dx, float* dy, void* stream);
 
 /* Measurement hook — no counterpart in the reference.  Arms the NEXT tvae_mmd_fwd_bwd call made
  * on this host thread: hipEventRecord(ev_start) / (ev_stop) are enqueued on that call's stream

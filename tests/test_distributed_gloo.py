@@ -158,16 +158,19 @@ def _prior_worker(rank, world, port, out):
         import transformer_vae_amd as amd
         cfg = SimpleNamespace(t5=SimpleNamespace(d_model=8), funnel=SimpleNamespace(d_model=8, layer_norm_eps=1e-9),
                               latent_size=3, n_latent_tokens=2)
-        torch.manual_seed(11)                                   # every rank alike, as the reference launcher
+        torch.manual_seed(11 + 5 * rank)                        # per-rank seeding (seed + rank): the base seed must still agree
         mk = lambda: amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](cfg), amd.VAE_DECODER_MODELS[""](cfg), True, mmd_scope="global")
         cpu = torch.device("cpu")
         a = mk()
         own1, own2 = a._draw_prior((4, 3), cpu), a._draw_prior((4, 3), cpu)
         b = mk()
         all1, all2 = b._draw_prior_all_ranks((4, 3), cpu), b._draw_prior_all_ranks((4, 3), cpu)
+        c = mk()                                                # the one-argument form first, then the replay: streams stay aligned
+        c._draw_prior((4, 3), cpu)
+        mixed = c._draw_prior_all_ranks((4, 3), cpu)
         blocks = [torch.empty_like(own1) for _ in range(world)]
         dist.all_gather(blocks, own1)
-        out.put((rank, own1.numpy(), own2.numpy(), all1.numpy(), all2.numpy(), torch.cat(blocks).numpy()))
+        out.put((rank, own1.numpy(), own2.numpy(), all1.numpy(), all2.numpy(), torch.cat(blocks).numpy(), mixed.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -184,7 +187,8 @@ def test_global_scope_prior_streams_differ_per_rank_and_replay_everywhere():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, o0, o0b, a0, a0b, g0), (_, o1, o1b, a1, a1b, g1) = res
+    (_, o0, o0b, a0, a0b, g0, m0), (_, o1, o1b, a1, a1b, g1, m1) = res
+    assert np.array_equal(m0, m1) and np.array_equal(m0, a0b)                  # same second draw on every rank, whichever form drew first
     assert not np.array_equal(o0, o1) and not np.array_equal(o0, o0b)          # ranks differ, draws advance
     assert np.array_equal(g0, np.concatenate([o0, o1])) and np.array_equal(g0, g1)
     # the all-rank replay is the gathered prior, on every rank, draw after draw: no all-gather needed

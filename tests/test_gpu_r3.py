@@ -1,0 +1,156 @@
+"""Round-3 GPU parity additions.
+
+* Adversarial input STRUCTURE for the split-fp16 MMD (the default for fp32 latents): the accuracy argument of the
+  one-/two-product Gram is statistical (column roundings independent and zero-mean), so these feed it inputs whose
+  roundings are coherent -- duplicated rows, latents quantised to a few levels, a collapsed posterior, a prior with a
+  common offset, one outlier row that crushes the fp16 scale for everybody else -- against fp64 on the GPU.
+  Bars: loss 1e-6, gradient 1e-5 of its maximum, and the error relative to the kernel-dependent part of the gradient
+  (the exact mean-shift term removed) within 2x of the strict fp32 kernel's own.
+* `_compute_kernel` as a materialised matrix and the `t5_norm` decoder's backward, against fixtures generated from the
+  imported reference (tests/golden/make_golden_r3.py)."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _fp64_truth(z, y):
+    """loss (unscaled MMD), full gradient d MMD / d z and its mean-shift part, torch fp64 on the GPU."""
+    z64, y64 = z.double(), y.double()
+    N, D = z64.shape
+    inv = 1.0 / float(D * D)
+    nz, ny = (z64 * z64).sum(1), (y64 * y64).sum(1)
+    tot = torch.zeros(3, dtype=torch.float64, device=z.device)
+    G = torch.zeros_like(z64)
+    R = torch.zeros(N, dtype=torch.float64, device=z.device)
+    for r0 in range(0, N, 2048):
+        sl = slice(r0, r0 + 2048)
+        Ezz = torch.expm1(-((nz[sl, None] + nz[None, :] - 2.0 * (z64[sl] @ z64.T)) * inv).clamp_min(0))
+        Ezy = torch.expm1(-((nz[sl, None] + ny[None, :] - 2.0 * (z64[sl] @ y64.T)) * inv).clamp_min(0))
+        Eyy = torch.expm1(-((ny[sl, None] + ny[None, :] - 2.0 * (y64[sl] @ y64.T)) * inv).clamp_min(0))
+        tot += torch.stack([Ezz.sum(), Ezy.sum(), Eyy.sum()])
+        G[sl] = Ezz @ z64 - Ezy @ y64
+        R[sl] = Ezz.sum(1) - Ezy.sum(1)
+    shift = (z64.sum(0) - y64.sum(0))[None, :]
+    c = 4.0 * inv / float(N * N)
+    grad = c * (-(z64 * R[:, None]) + shift + G)
+    return float((tot[2] + tot[0] - 2.0 * tot[1]) / float(N * N)), grad, c * shift
+
+
+def _structured(case, N, D):
+    gen = torch.Generator(device=dev()).manual_seed(1000 + N + D)
+    z = torch.tanh(torch.randn((N, D), generator=gen, device=dev()))
+    y = torch.randn((N, D), generator=gen, device=dev())
+    if case == "dup64":
+        z = z[: N // 64].repeat_interleave(64, 0)
+        y = y[: N // 64].repeat_interleave(64, 0)
+    elif case == "tern":
+        z = torch.round(z)
+    elif case == "lev8":
+        z = torch.round(z * 4) / 4
+    elif case == "collapsed":
+        z = z[:1].repeat(N, 1)
+    elif case == "prior+3":
+        y = y + 3.0
+    elif case == "outlier50":
+        z = z / z.norm(dim=1, keepdim=True)
+        y = y / y.norm(dim=1, keepdim=True)
+        z[17] *= 50.0
+    elif case == "both+5":
+        z, y = z + 5.0, y + 5.0
+    elif case == "both+50":
+        z, y = z + 50.0, y + 50.0
+    return z.contiguous(), y.contiguous()
+
+
+def _run(z, y, strict):
+    from transformer_vae_amd import functional as F
+    zt = z.clone().requires_grad_(True)
+    loss = F.mmd_reg_loss(zt, y, batch_size=1, n_latents=1, strict_fp32=strict)
+    loss.backward()
+    return float(loss.detach()), zt.grad.double()
+
+
+CASES = ["dup64", "tern", "lev8", "collapsed", "prior+3", "outlier50", "both+5", "both+50"]
+
+
+@pytest.mark.parametrize("D", [77, 256, 768, 1024])
+@pytest.mark.parametrize("case", CASES)
+def test_mmd_split_on_adversarially_structured_inputs(case, D):
+    N = 8192
+    z, y = _structured(case, N, D)
+    ref_loss, ref_grad, shift_part = _fp64_truth(z, y)
+    loss, grad = _run(z, y, strict=False)
+    loss_s, grad_s = _run(z, y, strict=True)
+    gmax = float(ref_grad.abs().max())
+    kmax = float((ref_grad - shift_part).abs().max())
+    err = float((grad - ref_grad).abs().max())
+    err_s = float((grad_s - ref_grad).abs().max())
+    info = dict(case=case, D=D, loss=loss, ref_loss=ref_loss, loss_err=abs(loss - ref_loss) / max(abs(ref_loss), 1e-300),
+                grad_err=err / gmax, kern_err=err / max(kmax, 1e-300), strict_kern_err=err_s / max(kmax, 1e-300),
+                strict_loss_err=abs(loss_s - ref_loss) / max(abs(ref_loss), 1e-300))
+    print(info)
+    # a collapsed posterior against itself has MMD(z, z) terms that are exactly 0; the loss is still O(1e-3)
+    assert abs(loss - ref_loss) <= 1e-6 * abs(ref_loss) + 1e-12, info
+    assert err <= 1e-5 * gmax, info
+    if kmax > 1e-3 * gmax:      # the finer yardstick only where the kernel-dependent part is not itself rounding noise
+        assert err <= max(2.0 * err_s, 1e-6 * kmax), info
+
+
+def test_compute_kernel_matches_the_reference_matrix_and_gradients():
+    import transformer_vae_amd as amd
+    g = np.load(os.path.join(GOLD, "compute_kernel_cases.npz"))
+    for ci in range(int(g["count"])):
+        x = torch.from_numpy(g[f"x{ci}"]).to(dev()).requires_grad_(True)
+        y = torch.from_numpy(g[f"y{ci}"]).to(dev()).requires_grad_(True)
+        K = amd.EncoderDecoderVAE._compute_kernel(x, y)
+        assert tuple(K.shape) == g[f"k{ci}"].shape and K.dtype == torch.float32
+        (K * torch.from_numpy(g[f"c{ci}"]).to(dev())).sum().backward()
+        kerr = np.abs(K.detach().cpu().numpy() - g[f"k{ci}"]).max()
+        assert kerr <= max(2e-6, 2.0 * float(g[f"k32err{ci}"])), (ci, kerr)      # values in (0, 1]; the reference's own fp32 run beside it
+        for got, want in ((x.grad, g[f"dx{ci}"]), (y.grad, g[f"dy{ci}"])):
+            e = np.abs(got.cpu().numpy() - want).max()
+            assert e <= 1e-5 * np.abs(want).max() + 1e-12, (ci, e, np.abs(want).max())
+    # the instance form the reference's _compute_mmd uses, and a CPU tensor fails loudly (no fallback)
+    cfg = SimpleNamespace(t5=SimpleNamespace(d_model=8), funnel=SimpleNamespace(d_model=8, layer_norm_eps=1e-9), latent_size=3,
+                          n_latent_tokens=2)
+    vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](cfg), amd.VAE_DECODER_MODELS[""](cfg))
+    k2 = vae._compute_kernel(torch.from_numpy(g["x0"]).to(dev()), torch.from_numpy(g["y0"]).to(dev()))
+    assert np.abs(k2.cpu().numpy() - g["k0"]).max() <= 2e-6
+    with pytest.raises(RuntimeError):
+        vae._compute_kernel(torch.from_numpy(g["x0"]), torch.from_numpy(g["y0"]))
+
+
+def test_t5_norm_decoder_backward_through_our_linear():
+    import transformer_vae_amd as amd
+    from transformers import T5Config
+    g = np.load(os.path.join(GOLD, "vae_t5norm_bwd.npz"))
+    B, S, d, n, L, _ = (int(v) for v in g["shape"])
+    dm, dff, dkv, nh = (int(v) for v in g["t5"])
+    cfg = SimpleNamespace(t5=T5Config(d_model=dm, d_ff=dff, d_kv=dkv, num_heads=nh),
+                          funnel=SimpleNamespace(d_model=d, layer_norm_eps=1e-9), latent_size=L, n_latent_tokens=n)
+    vae = amd.EncoderDecoderVAE(amd.VAE_ENCODER_MODELS[""](cfg), amd.VAE_DECODER_MODELS["t5_norm"](cfg))
+    vae.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")})
+    vae = vae.to(dev())
+    h = torch.from_numpy(g["h"]).to(dev()).requires_grad_(True)
+    out = vae(input_encoding=h, true_samples=torch.from_numpy(g["prior"]).to(dev()))
+    (out.reg_loss * float(g["reg_weight"]) + (out.reconstructed_encoding * torch.from_numpy(g["g0"]).to(dev())).sum()).backward()
+
+    def rel(a, b):
+        return float(np.abs(a.detach().cpu().numpy().astype(np.float64) - b).max() / np.abs(b).max())
+
+    assert rel(out.latent, g["latent"]) <= 1e-5
+    assert rel(out.reconstructed_encoding, g["recon"]) <= 1e-4          # stock HF block in fp32 against the fp64 fixture
+    assert rel(h.grad, g["dh"]) <= 1e-4
+    for name, p in vae.named_parameters():
+        # every gradient passes through the stock fp32 T5 block (1e-4 class, as its forward); our linear and encoder add 1e-5
+        assert rel(p.grad, g["grad_" + name]) <= 1e-4, name

@@ -99,6 +99,12 @@ def test_reg_weight_schedule_and_deferred_logs():
     assert out == pytest.approx({"decoder_ce": 3.0, "reg_loss": 1.0, "reg_loss_w": 0.2})
     logs.update(decoder_ce=torch.tensor(1.0), reg_loss=torch.tensor(0.0), reg_loss_w=0.5)
     assert logs.get_latest_logs() == pytest.approx({"decoder_ce": 1.0, "reg_loss": 0.0, "reg_loss_w": 0.5})
+    # the reference's trainer writes running totals from outside (trainer.py:341-376); a key that did not move reports 0
+    logs.update(decoder_ce=torch.tensor(2.0))
+    logs.latest_logs["cycle_loss"] = logs.latest_logs.get("cycle_loss", 0) + 0.75
+    logs.update(decoder_ce=torch.tensor(6.0))
+    assert logs.get_latest_logs() == pytest.approx({"decoder_ce": 4.0, "reg_loss": 0.0, "reg_loss_w": 0.0, "cycle_loss": 0.375})
+    assert logs.get_latest_logs() == {}                          # no update since: nothing to report, no division by zero
 
 
 def test_trainer_arguments_and_loss_grad():

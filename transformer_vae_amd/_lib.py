@@ -45,6 +45,8 @@ SIGNATURES = {
     "tvae_upsample_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _vp]),
     "tvae_upsample_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _int, _vp]),
     "tvae_slerp": (_int, [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _int, _vp]),
+    "tvae_rbf_kernel_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "tvae_rbf_kernel_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "tvae_mmd_fwd_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp, _i64, _vp]),
     "tvae_mmd_fwd_bwd_static": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp]),
     "tvae_small_step_supported": (_int, [_i64] * 4),

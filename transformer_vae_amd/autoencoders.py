@@ -150,6 +150,7 @@ class EncoderDecoderVAE(nn.Module):
         self.compensate_ddp_mean = (mmd_scope == "global") if compensate_ddp_mean is None else bool(compensate_ddp_mean)
         self.mmd_strict_fp32 = bool(mmd_strict_fp32)
         self._prior_generators = {}
+        self._prior_base_seed = None
         # encode -> MMD -> decode as one autograd node when the stock pair is used plainly (same kernels and
         # numbers; less Python autograd bookkeeping per eager step).  False keeps the three separate nodes.
         self.fuse_step = True
@@ -214,6 +215,12 @@ class EncoderDecoderVAE(nn.Module):
             reg_loss = torch.tensor(0, device=latent.device)
         return BaseVAE_Output(latent=latent, reconstructed_encoding=recon_encoding, reg_loss=reg_loss)
 
+    @staticmethod
+    def _compute_kernel(x, y):
+        """The (Nx, Ny) matrix exp(-mean((x_i - y_j)^2) / dim) of autoencoders.py:117-126, materialised and differentiable,
+        for callers that want the matrix itself.  ``forward`` never forms it: the regulariser regenerates kernel tiles."""
+        return F.rbf_kernel(x, y)
+
     def _compute_mmd(self, x, y):
         """MMD(x = prior samples, y = latents), unscaled (autoencoders.py:128-132); differentiable in y."""
         n, dim = y.shape
@@ -231,26 +238,41 @@ class EncoderDecoderVAE(nn.Module):
         """``torch.randn(latent.size())`` as the reference (:135), fp32 on the latent's device.
 
         Global scope: the reference launcher seeds every rank alike (train.py:391), so the default generator would hand
-        every rank the SAME block and the gathered prior would be R copies of it.  Each rank therefore draws from its
-        own stream, seeded ``torch.initial_seed() + 1 + rank`` (kept per device, advanced by every draw)."""
+        every rank the SAME block and the gathered prior would be R copies of it.  Each rank's block therefore comes from
+        its own stream (see ``_rank_generator``); every rank replays ALL streams in step (``_draw_prior_all_ranks``) and
+        keeps its own block, so the streams stay aligned across ranks whichever form of the call drew last."""
         if not self._global_scope_active():
             return torch.randn(size, device=device)
         import torch.distributed as dist
-        return torch.randn(size, device=device, generator=self._rank_generator(dist.get_rank(self.process_group), device))
+        rank = dist.get_rank(self.process_group)
+        n_local = int(size[0])
+        return self._draw_prior_all_ranks(size, device)[rank * n_local:(rank + 1) * n_local]
+
+    def _prior_base_seed_all_ranks(self, device):
+        """One base seed for the per-rank prior streams, the SAME on every rank: rank 0's ``torch.initial_seed()``,
+        broadcast once.  (With per-rank seeding, seed + rank, each rank would otherwise replay different streams and the
+        ranks' priors -- hence their losses and gradients -- would silently belong to different problems.)"""
+        if self._prior_base_seed is None:
+            import torch.distributed as dist
+            on_device = dist.get_backend(self.process_group) != "gloo"
+            t = torch.tensor([torch.initial_seed() & ((1 << 62) - 1)], dtype=torch.int64, device=device if on_device else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(self.process_group or dist.group.WORLD, 0), group=self.process_group)
+            self._prior_base_seed = int(t.item())
+        return self._prior_base_seed
 
     def _rank_generator(self, rank, device):
         key = (str(device), int(rank))
         gen = self._prior_generators.get(key)
         if gen is None:
             gen = torch.Generator(device=device)
-            gen.manual_seed(torch.initial_seed() + 1 + int(rank))
+            gen.manual_seed(self._prior_base_seed_all_ranks(device) + 1 + int(rank))
             self._prior_generators[key] = gen
         return gen
 
     def _draw_prior_all_ranks(self, size_local, device):
-        """Global scope, no caller prior: every rank replays the streams of ALL ranks (same seeds, advanced in step on
-        every rank), so the (N, D) prior exists everywhere without an all-gather.  Block r is exactly what rank r's
-        ``_draw_prior`` would have drawn."""
+        """Global scope, no caller prior: every rank replays the streams of ALL ranks (one base seed, broadcast from rank 0;
+        advanced in step on every rank), so the (N, D) prior exists everywhere without an all-gather.  Block r is rank
+        r's share.  Collective in spirit: every rank must make the same sequence of draws."""
         import torch.distributed as dist
         world = dist.get_world_size(self.process_group)
         return torch.cat([torch.randn(size_local, device=device, generator=self._rank_generator(r, device))

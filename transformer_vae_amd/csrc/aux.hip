@@ -278,6 +278,77 @@ extern "C" int tvae_upsample_bwd(const void* d_out, void* d_x, int64_t B, int64_
     return TVAE_OK;
 }
 
+// ---- _compute_kernel as a materialised (Nx, Ny) matrix (autoencoders.py:117-126), for callers that want the matrix itself
+// (notebooks, subclasses).  The training path never forms it: tvae_mmd_fwd_bwd regenerates tiles.  Direct-difference form
+// like the reference (sum of (x - y)^2, then / D / D, then exp), fp32; 16 x 16 outputs per workgroup, 32-feature LDS stages.
+namespace tvae {
+namespace {
+__global__ __launch_bounds__(256) void rbf_kernel_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, int nx, int ny,
+                                                            int D, float* __restrict__ K) {
+    __shared__ float xs[16][33], ys[16][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    float s = 0.f;
+    for (int c0 = 0; c0 < D; c0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e >> 5, c = e & 31;
+            xs[r][c] = (i0 + r < nx && c0 + c < D) ? x[(long long)(i0 + r) * D + c0 + c] : 0.f;
+            ys[r][c] = (j0 + r < ny && c0 + c < D) ? y[(long long)(j0 + r) * D + c0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float dlt = xs[ty][c] - ys[tx][c];
+            s = fmaf(dlt, dlt, s);
+        }
+        __syncthreads();
+    }
+    if (i0 + ty < nx && j0 + tx < ny) K[(long long)(i0 + ty) * ny + j0 + tx] = expf(-(s / (float)D) / (float)D);
+}
+
+// out[r][c] = -(2 / D^2) sum_q W(r, q) (a[r][c] - b[q][c]),  W(r, q) = gK[r sr + q sq] K[r sr + q sq]:
+// d<K, C>/dx with (a, b, sr, sq) = (x, y, ny, 1) and d/dy with (y, x, 1, ny).  One workgroup per row r.
+__global__ __launch_bounds__(256) void rbf_kernel_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ K,
+                                                            const float* __restrict__ gK, int nb, int D, long long sr, long long sq,
+                                                            float* __restrict__ out) {
+    const int r = blockIdx.x;
+    const float scale = -2.f / ((float)D * (float)D);
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float ac = a[(long long)r * D + c];
+        float acc = 0.f;
+        for (int q = 0; q < nb; ++q) {
+            const long long at = (long long)r * sr + (long long)q * sq;
+            acc = fmaf(gK[at] * K[at], ac - b[(long long)q * D + c], acc);
+        }
+        out[(long long)r * D + c] = scale * acc;
+    }
+}
+}  // namespace
+}  // namespace tvae
+
+extern "C" int tvae_rbf_kernel_fwd(const float* x, const float* y, int64_t nx, int64_t ny, int64_t D, float* K, void* stream) {
+    TVAE_REQUIRE(x && y && K, "rbf_kernel_fwd: null pointer argument");
+    TVAE_REQUIRE(nx > 0 && ny > 0 && D > 0 && nx < (1ll << 20) && ny < (1ll << 20) && D < (1ll << 24), "rbf_kernel_fwd: bad shape");
+    hipLaunchKernelGGL(tvae::rbf_kernel_fwd_kernel, dim3((unsigned)((ny + 15) / 16), (unsigned)((nx + 15) / 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, y, (int)nx, (int)ny, (int)D, K);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+extern "C" int tvae_rbf_kernel_bwd(const float* x, const float* y, const float* K, const float* gK, int64_t nx, int64_t ny, int64_t D,
+                                   float* dx, float* dy, void* stream) {
+    TVAE_REQUIRE(x && y && K && gK, "rbf_kernel_bwd: null pointer argument");
+    TVAE_REQUIRE(nx > 0 && ny > 0 && D > 0 && nx < (1ll << 20) && ny < (1ll << 20) && D < (1ll << 24), "rbf_kernel_bwd: bad shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dx) hipLaunchKernelGGL(tvae::rbf_kernel_bwd_kernel, dim3((unsigned)nx), dim3(256), 0, st, x, y, K, gK, (int)ny, (int)D,
+                               (long long)ny, 1ll, dx);
+    if (dy) hipLaunchKernelGGL(tvae::rbf_kernel_bwd_kernel, dim3((unsigned)ny), dim3(256), 0, st, y, x, K, gK, (int)nx, (int)D,
+                               1ll, (long long)ny, dy);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
 extern "C" int tvae_slerp(const void* t1, const void* t2, const float* ratios, float ratio, void* out, int64_t rows,
                           int64_t dim, int dtype, void* stream) {
     TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16, "slerp: unknown dtype %d", dtype);

@@ -1032,7 +1032,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
             p->sp_major = 1;
         }
     }
-#if defined(TVAE_PHASE_TIMING) || defined(TVAE_DEBUG_ENV)
+#ifdef TVAE_PHASE_TIMING
     if (getenv("TVAE_DEBUG_COL_SPLITS")) p->col_splits = atoi(getenv("TVAE_DEBUG_COL_SPLITS"));   // experiments only
 #endif
     int rpw = (p->n_pad + 511) / 512;
@@ -1061,9 +1061,6 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
         const int64_t groups = ((int64_t)p->row_blocks_g * p->col_splits + slots - 1) / slots;
         if (epochs >= 1 && slots % 8 == 0 && groups * epochs <= (1 << 17)) { p->sync_epochs = (int)epochs; p->sync_groups = (int)groups; }
     }
-#ifdef TVAE_DEBUG_ENV
-    if (getenv("TVAE_DEBUG_NO_SYNC")) p->sync_epochs = 0;          // experiments only
-#endif
     p->off_sync = take((int64_t)p->sync_groups * 8 * p->sync_epochs * 4);
     p->off_amax = take(p->split ? 256 + AMAX_BLOCKS * 4 : 0);      // the scale word, then the per-block maxima
     p->ldq = (int)align_up(D + 1, 4);
@@ -1329,9 +1326,6 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     a.inv_d2 = (float)(1.0 / ((double)D * (double)D));
     a.sp_major = (p.sync_epochs > 0 || p.sp_major) ? 1 : 0;     // a resident set then shares ONE column range
     a.sync_ctr = nullptr; a.sync_epochs = p.sync_epochs; a.sync_group = p.sync_group; a.launch_blocks = 0;
-#ifdef TVAE_DEBUG_ENV
-    if (getenv("TVAE_DEBUG_SP_MAJOR")) a.sp_major = atoi(getenv("TVAE_DEBUG_SP_MAJOR"));          // experiments only
-#endif
     const int sym_rows = p.n16 ? 16 * p.RT : ((p.narrow64 || p.pipe_sum) ? 64 : ROWS_PER_WG);      // row block of the symmetric y-y enumeration
     a.sym = (row_offset % sym_rows == 0 && (n_rows % sym_rows == 0 || row_offset + n_rows == n_total)) ? 1 : 0;
     a.wg_sums = reinterpret_cast<double*>(ws + p.off_sums);

@@ -200,11 +200,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
     auto step_src = [&](int v) -> Src {
         const int u = actual(v);
         const int set = u >= nJ ? 1 : 0;
-#ifdef TVAE_DEBUG_SAME_TILE
-        const int p0 = 0 * u;                    // experiment: every step streams the same (cache-hot) tile
-#else
         const int p0 = (u - set * nJ) * STEP_P;
-#endif
         const long long off = (long long)p0 * DPAD + wave * SW;
         return Src{reinterpret_cast<const bf16*>(a.cols[set]) + off,
                    SPLIT ? reinterpret_cast<const bf16*>(a.cols_lo[set]) + off : nullptr};
@@ -351,12 +347,6 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
                 sv[j][r] = tt;
                 tmax = fmaxf(tmax, tt);
             }
-#ifdef TVAE_DEBUG_CHEAP_E
-        if (true) {                              // experiment: no expm1 arithmetic
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) { e[j] = sv[j]; q[j] = sv[j]; }
-        } else
-#endif
         if (!__any(tmax >= EM1_TINY)) {
 #pragma unroll
             for (int j = 0; j < TPW; ++j)

@@ -60,7 +60,12 @@ __global__ __launch_bounds__(64 * N16_WAVES, N16_WPE(KBN, RT)) void mmd_n16_kern
     // Gram products (mmd_common.h, TVAE_GRAM_PRODUCTS): the error of the two-product form grows as the width shrinks (the
     // 1 / D^2 in t no longer hides it; measured gradient error against fp64: 2e-7 at D = 192, 6e-7 at 77, 2.4e-6 at 32,
     // 1e-5 at 8), so widths up to 64 keep all three
-    constexpr int GP = KBN >= 3 ? TVAE_GRAM_PRODUCTS : 3;
+    // Round 3: ALL three products at every width of this kernel.  The two-product form (column side hi only) held 1e-5 on
+    // i.i.d. data but not on structured inputs at D = 77 (tests/test_gpu_r3.py, N = 8 192, against fp64): rows duplicated
+    // 64x, latents quantised to 3 or 8 levels and one outlier row gave 5 - 16x the strict fp32 kernel's error on the
+    // kernel-dependent part of the gradient and 6.7e-6 on the loss -- with 77 features there are too few roundings per dot
+    // product to average out.  Cost at BASELINE cfg3: 79.5 -> 84.5 us for the kernel.
+    constexpr int GP = 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
     const unsigned sm_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;

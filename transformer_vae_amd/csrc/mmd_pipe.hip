@@ -75,6 +75,10 @@ struct PipeLds {
 #define TVAE_PIPE_GD 1
 #endif
 
+#ifndef TVAE_Q32
+#define TVAE_Q32 1
+#endif
+
 template <int V> using ic = std::integral_constant<int, V>;
 
 // QF (split only): the Q-form instance. The device-side switch QFlag (mmd.hip) selects ONE of the two instances of a
@@ -206,11 +210,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     auto step_meta = [&](int v, int& set, int& p0) {
         const int u = v < se ? v : se - 1;                    // past the end: the last step again (results unused)
         set = u >= nS ? 1 : 0;
-#ifdef TVAE_DEBUG_SAME_TILE
-        p0 = 0 * u;
-#else
         p0 = (u - (set ? nS : 0)) * P;
-#endif
     };
     // both sets' bases in scalar registers, picked by a scalar select (indexing a.cols[set] is a scalar memory load
     // per step, and hipcc then did the pointer arithmetic in vector registers: ~25 instructions per step)
@@ -273,11 +273,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         for (int j = 0; j < TPW; ++j)
 #pragma unroll
             for (int w = 0; w < 3; ++w) {
-#ifdef TVAE_DEBUG_NO_XCH
-                part[j][w] = S[0][j];
-#else
                 part[j][w] = xb[((wave * TPW + j) * 3 + w) * 64 + lane];     // all reads in flight
-#endif
             }
         cn = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + ((nbuf * 4 + wave) * 64 + 16 * my_pt + 4 * g) * 4);
     };
@@ -446,9 +442,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
                     for (int pt = 0; pt < PT; ++pt) S[pt][t] = mma<SPLIT>(al[s][pt], zreg[t][s], S[pt][t]);
 #endif
             }
-#ifndef TVAE_DEBUG_NO_E
             if constexpr (WITH_E) e_slice(s);
-#endif
         }
     };
 
@@ -539,11 +533,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
     bool slow_c = true;
     // one interval; the buffer indices are compile-time constants (the loop below is unrolled by two)
     auto interval = [&](int k, auto cur_tag) {
-#ifdef TVAE_PIPE_UNROLL2
-        constexpr int cur = decltype(cur_tag)::value, nxt = cur ^ 1;
-#else
         const int cur = k & 1, nxt = cur ^ 1;
-#endif
         // point-tile slots: this tile's, the next one's (Gram), the one to fill; norm buffers go with the slots
         const int xs_cur = RING ? (k & 3) : cur, xs_nxt = RING ? ((k + 1) & 3) : nxt, xs_fill = RING ? ((k + 3) & 3) : cur;
         constexpr int FSLACK = RING ? 1 + DPS * KB : 0;
@@ -558,9 +548,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
         PHASE_MARK(0);
         // the barrier needs the partials' WRITES retired, not the gradient's operand reads: LDS operations retire in
         // order, so with the reads issued behind the writes a counted wait leaves them in flight across the barrier
-#ifndef TVAE_DEBUG_NO_XCH
         xch_write(nxt);
-#endif
         asm volatile("" ::: "memory");          // the reads below stay behind the writes (the count depends on it)
         __builtin_amdgcn_sched_barrier(0);
         grad_fetch_x(xs_cur);
@@ -570,9 +558,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
         }
         PHASE_MARK(1);
-#ifndef TVAE_DEBUG_NO_BARRIER
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
         PHASE_MARK(2);
         // gradient of this tile (+ refill with tile k + 2)  ||  reduce of the next tile's partials
@@ -619,14 +605,7 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
             Xn2_c = step_src(sb + (RING ? 3 : 2));
             slow_c = any_invalid || t_big || c_p0_c + P > a.n_cols;
         }
-#ifdef TVAE_PIPE_UNROLL2
-        for (int k = 0; k < nsteps; k += 2) {
-            interval(k, ic<0>{});
-            if (k + 1 < nsteps) interval(k + 1, ic<1>{});
-        }
-#else
         for (int k = 0; k < nsteps; ++k) interval(k, ic<0>{});
-#endif
     }
     wait_vmcnt<0>();
 #ifdef TVAE_PHASE_TIMING
@@ -1038,6 +1017,9 @@ int launch_pipe(const MmdArgs& a, int nblocks, hipStream_t s) {
     TVAE_CHECK_HIP(hipGetLastError());
     if constexpr (SPLIT) {
         if (a.qflag != nullptr) {          // the pair: exactly one of the two does the work (QFlag)
+#if TVAE_Q32
+            return launch_mmd_q32(KB, a, nblocks, s);      // round 3: one-product, 32-point, all-32x32x16 Q-form kernel (mmd_q32.hip)
+#endif
             static PerDeviceOnce once_q;
             TVAE_CHECK_HIP(per_device_once(once_q, [] {
                 return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_pipe_kernel<KB, SPLIT, true>),

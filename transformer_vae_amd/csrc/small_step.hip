@@ -755,9 +755,6 @@ extern "C" int tvae_small_step_fwd(const void* h, int64_t h_stride_b, int64_t h_
     a.zn = (float*)(ws + w.zn); a.yn = (float*)(ws + w.yn); a.ticket = (unsigned*)(ws + w.ticket);
     a.N = (int)N; a.n_eff = (int)n_eff; a.d = (int)d; a.L = (int)L; a.JT = s.JT;
     a.stop = 0;
-#ifdef TVAE_DEBUG_ENV
-    if (getenv("TVAE_SMALL_DEBUG_STOP")) a.stop = atoi(getenv("TVAE_SMALL_DEBUG_STOP"));      // phase timing experiments only
-#endif
     const int blocks = (int)((N + s.RPB - 1) / s.RPB);
     static PerDeviceOnce o1, o2, o3;
     if (s.RPB == 1) {

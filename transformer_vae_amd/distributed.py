@@ -50,7 +50,7 @@ def all_reduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def sharded_mmd_reg_loss(latent2d: torch.Tensor, prior_local: Optional[torch.Tensor], batch_size_local: int, n_latents: int,
-                         group=None, compensate_ddp_mean: bool = True,
+                         group=None, compensate_ddp_mean: bool = False,
                          row_block_fn: Optional[Callable] = None, strict_fp32: bool = False,
                          prior_all: Optional[torch.Tensor] = None) -> torch.Tensor:
     """reg_loss of the GLOBAL batch; every rank returns the same value.
@@ -61,8 +61,8 @@ def sharded_mmd_reg_loss(latent2d: torch.Tensor, prior_local: Optional[torch.Ten
     The gradient that flows into ``latent2d`` is d(global reg)/d(local rows), complete.
     ``compensate_ddp_mean``: DDP averages parameter gradients over R ranks while each rank
     holds only its rows' share of the global loss gradient; multiplying the local gradient
-    by R makes the averaged result equal the single-process global-batch gradient (default; pass False when the
-    gradients are summed across ranks instead)."""
+    by R makes the averaged result equal the single-process global-batch gradient.  Default False (gradients summed
+    across ranks, or no DDP at all); EncoderDecoderVAE passes True under global scope, where DDP is the caller."""
     fn = row_block_fn or (lambda *a: F.mmd_row_block(*a, strict_fp32))
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)

@@ -278,8 +278,9 @@ class _BottleneckStep(torch.autograd.Function):
         want_grad = bool(grad_enabled) and any(ctx.needs_input_grad[:3])
         ctx.small = False
         if (SMALL_STEP and 0 < N <= SMALL_STEP_MAX_ROWS and dt == torch.float32 and has_lin and has_ln and prior.dtype == torch.float32
-                and lib.tvae_small_step_supported(B, n_eff, d, L) and hc.stride(0) % 4 == 0 and hc.stride(1) % 4 == 0
-                and hc.data_ptr() % 16 == 0):
+                and not strict_fp32 and lib.tvae_small_step_supported(B, n_eff, d, L) and hc.stride(0) % 4 == 0
+                and hc.stride(1) % 4 == 0
+                and all(t.data_ptr() % 16 == 0 for t in (hc, Wc, bc, Wd, bd, gamma, beta) if t.is_contiguous())):
             # the reference's own batch sizes: the whole forward in two launches (csrc/small_step.hip)
             Wdc, bdc, gc, btc = Wd.contiguous(), bd.contiguous(), gamma.contiguous(), beta.contiguous()
             ya = prior.reshape(N, L).contiguous()
@@ -452,6 +453,46 @@ class _Upsample(torch.autograd.Function):
         return (dx if dt == x_dtype else dx.to(x_dtype)), None, None, None, None
 
 
+class _RbfKernel(torch.autograd.Function):
+    """K[i, j] = exp(-mean_c((x_i - y_j)^2) / dim), materialised (reference: autoencoders.py:117-126)."""
+
+    @staticmethod
+    @_on_tensor_device
+    def forward(ctx, x, y):
+        _require_device(x, "_compute_kernel")
+        _require_device(y, "_compute_kernel")
+        if x.dim() != 2 or y.dim() != 2 or x.shape[1] != y.shape[1]:
+            raise ValueError(f"_compute_kernel expects (Nx, D) and (Ny, D), got {tuple(x.shape)} and {tuple(y.shape)}")
+        out_dtype = torch.promote_types(x.dtype, y.dtype)
+        xc, yc = x.detach().float().contiguous(), y.detach().float().contiguous()
+        nx, dim = xc.shape
+        ny = yc.shape[0]
+        K = torch.empty((nx, ny), dtype=torch.float32, device=x.device)
+        if nx * ny * dim > 0:
+            _lib.check(_lib.lib().tvae_rbf_kernel_fwd(_ptr(xc), _ptr(yc), nx, ny, dim, _ptr(K), _stream(xc)), "tvae_rbf_kernel_fwd")
+        elif nx * ny > 0:
+            K.fill_(float("nan"))            # the reference takes the mean over an empty feature axis: nan
+        ctx.save_for_backward(xc, yc, K)
+        ctx.dtypes = (x.dtype, y.dtype)
+        return K if out_dtype == torch.float32 else K.to(out_dtype)
+
+    @staticmethod
+    @_on_tensor_device
+    def backward(ctx, gK):
+        xc, yc, K = ctx.saved_tensors
+        nx, dim = xc.shape
+        ny = yc.shape[0]
+        need_x, need_y = ctx.needs_input_grad
+        g = gK.float().contiguous()
+        dx = torch.zeros_like(xc) if need_x else None
+        dy = torch.zeros_like(yc) if need_y else None
+        if nx * ny * dim > 0:
+            _lib.check(_lib.lib().tvae_rbf_kernel_bwd(_ptr(xc), _ptr(yc), _ptr(K), _ptr(g), nx, ny, dim, _ptr(dx), _ptr(dy),
+                                                      _stream(xc)), "tvae_rbf_kernel_bwd")
+        cast = lambda t, to: None if t is None else (t if t.dtype == to else t.to(to))
+        return cast(dx, ctx.dtypes[0]), cast(dy, ctx.dtypes[1])
+
+
 # ------------------------------------------------------------------------------------------
 # functional API used by the modules in autoencoders.py
 # ------------------------------------------------------------------------------------------
@@ -462,6 +503,11 @@ def latent_encode(h, weight, bias, n_tokens: int):
 
 def latent_decode(z, weight=None, bias=None, ln_weight=None, ln_bias=None, eps: float = 1e-5):
     return _LatentDecode.apply(z, weight, bias, ln_weight, ln_bias, float(eps))
+
+
+def rbf_kernel(x, y):
+    """The (Nx, Ny) kernel matrix of the reference's ``_compute_kernel`` (autoencoders.py:117-126), differentiable."""
+    return _RbfKernel.apply(x, y)
 
 
 def mmd_scales(batch_size: int, n_latents: int, n_total: int, dim: int):

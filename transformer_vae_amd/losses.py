@@ -39,19 +39,25 @@ def combine_loss(decoder_ce: torch.Tensor, reg_loss: torch.Tensor, reg_loss_w: f
 class DeferredLogs:
     """Drop-in for the `latest_logs` bookkeeping of model.py:59-67,111-134 without per-step `.item()`.
 
-    Device scalars are added IN PLACE into persistent fp64 accumulators on their device (one per key, plus a call
-    counter), so `update` neither synchronises nor allocates after its first call and can sit inside a step captured
-    by `graph.GraphedStep`: every replay advances the sums and the counter.  `get_latest_logs` reads all of them
-    back in ONE transfer, returns the means over the window (the reference's numbers) and zeroes the window:
-    a logged value is never the difference of two ever-growing sums.  `latest_logs` keeps the reference's running
-    totals as Python doubles, refreshed at each readback."""
+    Contract kept from the reference: `latest_logs` holds running totals per key and may be written from outside
+    (trainer.py:341-376 does `model.latest_logs['cycle_loss'] = ... + x.item()`); `get_latest_logs` returns, for EVERY key
+    of `latest_logs`, the increase since the previous call divided by the number of updates since then (keys that did
+    not move report 0), and {} when there was no update.
+
+    What differs: device scalars passed to `update` are added IN PLACE into persistent fp64 accumulators on their device
+    (one per key, plus a call counter), so `update` neither synchronises nor allocates after its first call and can sit
+    inside a step captured by `graph.GraphedStep` (every replay advances the sums and the counter).  `get_latest_logs`
+    folds those windows into `latest_logs` with ONE readback -- and none at all when no device value was added since
+    the last call (unless an update was captured into a graph, whose replays the host cannot see)."""
 
     def __init__(self):
         self.latest_logs: Dict[str, Number] = {}
+        self._last_logs: Dict[str, float] = {}
         self._calls_since_last_log = 0          # host-side count (updates made by Python, not graph replays)
         self._window: Dict[str, torch.Tensor] = {}     # key -> fp64 scalar on the value's device, sum over the window
-        self._host_window: Dict[str, float] = {}
         self._counter: Dict[torch.device, torch.Tensor] = {}   # device -> fp64 scalar, updates seen by that device
+        self._device_dirty = False              # a device value was added since the last readback
+        self._captured = False                  # an update ran under stream capture: replays advance the windows unseen
 
     def update(self, **logs: Number) -> None:
         self._calls_since_last_log += 1
@@ -64,6 +70,7 @@ class DeferredLogs:
                     acc = torch.zeros((), dtype=torch.float64, device=v.device)
                     self._window[k] = acc
                 acc.add_(v.reshape(()))                        # in place: no allocation, no synchronisation
+                self._device_dirty = True
                 if v.device not in seen:
                     seen.add(v.device)
                     cnt = self._counter.get(v.device)
@@ -71,40 +78,36 @@ class DeferredLogs:
                         cnt = torch.zeros((), dtype=torch.float64, device=v.device)
                         self._counter[v.device] = cnt
                     cnt.add_(1.0)
+                    if v.is_cuda and torch.cuda.is_current_stream_capturing():
+                        self._captured = True
+                self.latest_logs.setdefault(k, 0.0)
             else:
-                self._host_window[k] = self._host_window.get(k, 0.0) + float(v)
-            self.latest_logs.setdefault(k, 0.0)
+                self.latest_logs[k] = self.latest_logs.get(k, 0.0) + v     # model.py:113-114
 
     def get_latest_logs(self) -> Dict[str, float]:
-        if self._calls_since_last_log < 1 and not self._counter:
-            return {}
-        # one readback for everything that lives on a device
-        keys = list(self._window)
-        devs = list(self._counter)
-        calls_dev: Dict[torch.device, float] = {}
-        sums: Dict[str, float] = {}
-        if keys or devs:
-            target = (self._window[keys[0]] if keys else self._counter[devs[0]]).device
+        calls_dev = 0.0
+        if self._counter and (self._device_dirty or self._captured):
+            # one readback for everything that lives on a device
+            keys = list(self._window)
+            devs = list(self._counter)
+            target = self._counter[devs[0]].device
             packed = torch.stack([self._window[k].to(target) for k in keys] + [self._counter[d].to(target) for d in devs])
             host = packed.cpu().tolist()
-            sums = dict(zip(keys, host[:len(keys)]))
-            calls_dev = dict(zip(devs, host[len(keys):]))
-            for k in keys:
+            for k, total in zip(keys, host[:len(keys)]):
+                self.latest_logs[k] = float(self.latest_logs.get(k, 0.0)) + total
                 self._window[k].zero_()
+            # graph replays advance the device counters but not the host one: the largest device count is the truth
+            calls_dev = max(host[len(keys):]) if devs else 0.0
             for d in devs:
                 self._counter[d].zero_()
-        if self._calls_since_last_log < 1 and not any(c > 0 for c in calls_dev.values()):
+            self._device_dirty = False
+        n = calls_dev if calls_dev > 0 else float(self._calls_since_last_log)
+        if n < 1:
             return {}
         result = {}
-        for k, total in sums.items():
-            # graph replays advance the device counter but not the host one: the device's count is the truth
-            n = calls_dev.get(self._window[k].device, 0.0) or float(self._calls_since_last_log)
-            result[k] = total / n
-            self.latest_logs[k] = float(self.latest_logs.get(k, 0.0)) + total
-        host_calls = max(self._calls_since_last_log, 1)
-        for k, total in self._host_window.items():
-            result[k] = total / host_calls
-            self.latest_logs[k] = float(self.latest_logs.get(k, 0.0)) + total
-        self._host_window = {}
+        for k, v in self.latest_logs.items():                      # model.py:126-129
+            v = float(v)
+            result[k] = (v - self._last_logs.get(k, 0.0)) / n
+            self._last_logs[k] = v
         self._calls_since_last_log = 0
         return result
