@@ -53,14 +53,11 @@ struct Q32Lds {
     static_assert(XCH_ONE_B >= (8 + 4 * 64) * 8, "final reduction reuses an exchange buffer");
 };
 
-__device__ __forceinline__ int q32_swz(int q) { return (2 * (q & 1)) ^ ((q >> 1) & 1) ^ (3 * ((q >> 2) & 1)); }
+#ifndef TVAE_Q32_DIAG
+#define TVAE_Q32_DIAG 0       // timing diagnostics (results are wrong): 1 no Q work, 2 no Gram operand reads, 3 no foreign stores, 4 same tile every step
+#endif
 
-#ifndef TVAE_Q32_TD
-#define TVAE_Q32_TD 2       // gradient operand reads run this many feature blocks ahead
-#endif
-#ifndef TVAE_Q32_GD
-#define TVAE_Q32_GD 2       // Gram operand reads run this many k-steps ahead
-#endif
+__device__ __forceinline__ int q32_swz(int q) { return (2 * (q & 1)) ^ ((q >> 1) & 1) ^ (3 * ((q >> 2) & 1)); }
 
 template <int KB>
 __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
@@ -110,7 +107,6 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) asm volatile("" : "+v"(zreg[b][ks]));
     asm volatile("" : "+v"(rnx));
-    const bool any_invalid = __any(!row_valid);
 
     f32x16 acc[KB][2];                                        // gradient: [32-feature block][ACTUAL 32-row block]
 #pragma unroll
@@ -160,249 +156,385 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
                 tr_off[kk][j] = 1024 * kk + 64 * (pt & 15) + 16 * ((2 * (g & 1) + (tp >> 1)) ^ q32_swz(pt >> 2)) + 8 * (tp & 1);
             }
     }
-    auto tr_read = [&](int byte_off) -> q_s16x4 {
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) q_s16x4*)(__attribute__((address_space(3))) char*)(sm + byte_off));
+    // LDS is addressed by 32-bit byte addresses that already include the base of the dynamic segment (pointer arithmetic on
+    // `smem` costs one vector addition of the -- relocated, zero -- segment base per access)
+#define Q32_LDS(T, addr) (*reinterpret_cast<__attribute__((address_space(3))) T*>((unsigned)(addr)))
+    const int lds0 = (int)smem_byte;
+    auto tr_read = [&](int addr) __attribute__((always_inline)) -> q_s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) q_s16x4*>((unsigned)addr));
     };
 
     struct Src { const _Float16* x; const float* nrm; };
-    auto step_meta = [&](int v, int& set, int& p0) {
+    auto step_meta = [&](int v, int& set, int& p0) __attribute__((always_inline)) {
         const int u = v < se ? v : se - 1;                    // past the end: the last step again (results unused)
         set = u >= nS ? 1 : 0;
+#if TVAE_Q32_DIAG == 4
+        p0 = 0 * u;           // timing diagnostic: every step fetches the same tile
+#else
         p0 = (u - (set ? nS : 0)) * P;
+#endif
     };
     const _Float16* const cbase0 = reinterpret_cast<const _Float16*>(a.cols[0]) + wave * SW;
     const _Float16* const cbase1 = reinterpret_cast<const _Float16*>(a.cols[1]) + wave * SW;
     const float* const nbase0 = a.cnorm[0];
     const float* const nbase1 = a.cnorm[1];
-    auto step_src = [&](int v) -> Src {
+    auto step_src = [&](int v) __attribute__((always_inline)) -> Src {
         int set, p0;
         step_meta(v, set, p0);
         const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(p0) * (unsigned)DPAD;   // the plan keeps n_pad * DPAD < 2^31
         return Src{(set ? cbase1 : cbase0) + off, (set ? nbase1 : nbase0) + p0};
     };
-    auto xbuf_byte = [&](int b) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
-    auto stage_norms = [&](const Src& X, int nbuf) {
+    auto xbuf_byte = [&](int b) __attribute__((always_inline)) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
+    auto stage_norms = [&](const Src& X, int nbuf) __attribute__((always_inline)) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(L::NORM_OFF + (nbuf * 4 + wave) * 64 * 4));
         dma4(uniform_ptr(X.nrm), (unsigned)lane * 4u, dst);
     };
-    auto dma_block = [&](const Src& X, int b, int s) {
+    auto dma_block = [&](const Src& X, int b, int s) __attribute__((always_inline)) {
         dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff0, dma_voff1, smem_byte + xbuf_byte(b) + 2048u * s);
     };
+    // L2 prefetch.  The refill of a block is issued ~700-1000 cycles before its first use (the buffer holds the step under
+    // the gradient until then) -- enough for an L2 hit, not for the Infinity Cache or HBM behind it (timing diagnostic with
+    // every step fetching the same tile: 3 950 -> 2 900 cycles per step).  So each wave touches the lines of ITS slice of the
+    // step PFD steps ahead with two plain loads (one dword per 128-byte line: 32 points x 3 lines of 192 features) into a
+    // register nothing reads.  They are issued behind the interval's last LDS-DMA, so the counted waits of the next Gram
+    // allow them in flight (PF_SLACK) and they have a whole interval to land before anything waits on something younger.
+    constexpr int PFD = 4, PF_OPS = (32 * ((SW * 2 + 127) / 128) + 63) / 64, PF_SLACK = PF_OPS;
+    unsigned pf_voff[PF_OPS];
+#pragma unroll
+    for (int i = 0; i < PF_OPS; ++i) {
+        constexpr int LPP = (SW * 2 + 127) / 128;             // 128-byte lines per point in a wave's slice
+        int idx = 64 * i + lane;
+        if (idx >= 32 * LPP) idx = 32 * LPP - 1;
+        pf_voff[i] = (unsigned)((idx / LPP) * DPAD * 2 + (idx % LPP) * 128);
+    }
+    float pf_sink = 0.f;
+    auto l2_prefetch = [&](const Src& X) __attribute__((always_inline)) {
+        const float* sbase = uniform_ptr(reinterpret_cast<const float*>(X.x));
+#pragma unroll
+        for (int i = 0; i < PF_OPS; ++i)
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_voff[i]), "s"(sbase) : "memory");
+    };
 
+    // ------------------------------------------------------------------------------------------------------------------
+    // The loop body is written as SLOTS: one matrix instruction, then the few other instructions that issue in its shadow
+    // (a 32x32x16 occupies the matrix pipe for 32 cycles and the vector issue port for 8 of them: ~5 single-issue
+    // instructions per slot are free, MI355X_MICROARCH.md).  hipcc clusters matrix instructions when left alone, and every
+    // LDS-DMA / counted wait here is an asm statement it does not schedule across anyway, so each slot is pinned with
+    // sched_barrier(0) on both sides: the instruction stream is the source order.  (First version of this kernel, one
+    // region per k-step / feature block: 7.24 ms at N = 32 768, D = 768; its phase timer showed 1 400 and 1 600 cycles for
+    // the two 768-cycle matrix phases and 900 cycles of exchange / barrier / fetch with the matrix pipe idle.)
+    // ------------------------------------------------------------------------------------------------------------------
+#define Q32_PIN() __builtin_amdgcn_sched_barrier(0)
+
+    constexpr int NS = 2 * NK;                                // Gram slots: pass 0 = local row block 1 (all foreign), pass 1 = block 0
+    constexpr int GD = 6, RING = 8;                           // Gram operand reads run GD slots ahead, in a ring of RING registers
+    static_assert(NS >= 8 && GD < RING && 4 * KB >= 8, "slot schedule");
+    // Per-lane LDS addresses of a buffer's operands, worked out ONCE per interval and pinned in registers (hipcc otherwise
+    // re-adds buffer base + lane offset in front of every read: 46 vector additions per step, 8 cycles each on a lone wave)
+    struct Bases { int g[2]; int t[2][2]; int xw[3]; int xr; int nr; int ew; int er; };
+    // chunk c = 0, 1, 2 of the exchange stores: local (block, half) = (1, 0), (1, 1), (0, 1)
+    int xw_off[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int b = c < 2 ? 1 : 0, hf = c == 0 ? 0 : 1;
+        const int owner = 2 * (b ^ wr) + (hf ^ wp);                          // wave-uniform
+        xw_off[c] = lds0 + L::XCH_OFF + lane * 16 + ((owner * 3 + ((wave - owner - 1) & 3)) * 2) * 1024;
+    }
+    const int xr_off = lds0 + L::XCH_OFF + lane * 16 + wave * 3 * 2 * 1024;
+    const int nr_off = lds0 + L::NORM_OFF + (wave * 64 + 16 * wp + 4 * h) * 4;
+    const int ew_off = lds0 + L::EBUF_OFF + (wp * 2 + wr) * 1024 + lane * 16;
+    const int er_off = lds0 + L::EBUF_OFF + lane * 16;
+    // `b`: the step buffer (and norm / E buffer) of that parity; the exchange buffer in use is always the OTHER parity's
+    // the addresses the Gram side of an interval uses (step buffer, exchange buffer and norms of parity b) ...
+    auto gram_bases = [&](int b) __attribute__((always_inline)) -> Bases {
+        Bases r{};
+        const int xb0 = lds0 + (int)xbuf_byte(b);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { r.g[i] = xb0 + gram_off[i]; asm volatile("" : "+v"(r.g[i])); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { r.xw[c] = xw_off[c] + b * L::XCH_ONE_B; asm volatile("" : "+v"(r.xw[c])); }
+        r.xr = xr_off + b * L::XCH_ONE_B; asm volatile("" : "+v"(r.xr));
+        r.nr = nr_off + b * 4 * 64 * 4; asm volatile("" : "+v"(r.nr));
+        return r;
+    };
+    // ... and the gradient side (step buffer read transposed, Q pieces of parity b; g: slots 0 .. GD-1 of the next Gram)
+    auto grad_bases = [&](int b) __attribute__((always_inline)) -> Bases {
+        Bases r{};
+        const int xb0 = lds0 + (int)xbuf_byte(b);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { r.t[kk][j] = xb0 + tr_off[kk][j]; asm volatile("" : "+v"(r.t[kk][j])); }
+        r.ew = ew_off + b * L::EBUF_ONE_B; asm volatile("" : "+v"(r.ew));
+        r.er = er_off + b * L::EBUF_ONE_B; asm volatile("" : "+v"(r.er));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r.g[i] = xb0 + gram_off[i];
+        return r;
+    };
     f32x16 S[2];                                              // partial Gram of the step in flight, local (rotated) order
-    // reduce-scatter: local (block b', half hf') is actual (b' ^ wr, hf' ^ wp), finished by wave 2 (b' ^ wr) + (hf' ^ wp)
-    auto xch_write = [&](int xbuf) {
-        char* xb = sm + L::XCH_OFF + xbuf * L::XCH_ONE_B + lane * 16;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                if (b == 0 && hf == 0) continue;
-                const int owner = 2 * (b ^ wr) + (hf ^ wp);                  // wave-uniform scalar arithmetic
-                char* dst = xb + ((owner * 3 + ((wave - owner - 1) & 3)) * 2) * 1024;
-                *reinterpret_cast<f32x4*>(dst) = f32x4{S[b][8 * hf], S[b][8 * hf + 1], S[b][8 * hf + 2], S[b][8 * hf + 3]};
-                *reinterpret_cast<f32x4*>(dst + 1024) = f32x4{S[b][8 * hf + 4], S[b][8 * hf + 5], S[b][8 * hf + 6], S[b][8 * hf + 7]};
-            }
+    q_f16x8 ab[RING];                                         // slots 0 .. GD-1 of the NEXT Gram are read at the end of an interval
+    // reduce-scatter: local (block b', half hf') is actual (b' ^ wr, hf' ^ wp), finished by wave 2 (b' ^ wr) + (hf' ^ wp);
+    // one 16-byte store = registers 8 hf + 4 q .. + 3
+    auto xch_store = [&](const Bases& B, int c, int q) __attribute__((always_inline)) {
+        const int b = c < 2 ? 1 : 0, hf = c == 0 ? 0 : 1;
+        Q32_LDS(f32x4, B.xw[c] + q * 1024) = f32x4{S[b][8 * hf + 4 * q], S[b][8 * hf + 4 * q + 1], S[b][8 * hf + 4 * q + 2], S[b][8 * hf + 4 * q + 3]};
     };
     float xv[8];                                              // x = -t of the eight S' entries this lane finishes
-    f32x4 part[3][2], cn[2];
-    auto xch_fetch = [&](int xbuf, int nbuf) {
-        const char* xb = sm + L::XCH_OFF + xbuf * L::XCH_ONE_B + lane * 16;
+    // the three remote partial sums and the point norms of registers 4 q .. 4 q + 3 (q = 0, 1: fetched and finished one
+    // after the other -- 16 registers in flight instead of 32)
+    f32x4 part[3], cn;
+    auto xch_fetch = [&](const Bases& B, int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) part[w][q] = *reinterpret_cast<const f32x4*>(xb + ((wave * 3 + w) * 2 + q) * 1024);
-        // register r = 4 j + i of this lane is point 16 wp + 8 j + 4 h + i
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            cn[j] = *reinterpret_cast<const f32x4*>(sm + L::NORM_OFF + ((nbuf * 4 + wave) * 64 + 16 * wp + 8 * j + 4 * h) * 4);
+        for (int w = 0; w < 3; ++w) part[w] = Q32_LDS(const f32x4, B.xr + (w * 2 + q) * 1024);
+        // register r = 4 q + i of this lane is point 16 wp + 8 q + 4 h + i
+        cn = Q32_LDS(const f32x4, B.nr + 8 * q * 4);
     };
-    auto xch_finish = [&]() {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {          // own partial (still in registers) + the three others, fixed order
-            const float sv = ((S[0][r] + part[0][r >> 2][r & 3]) + part[1][r >> 2][r & 3]) + part[2][r >> 2][r & 3];
-            xv[r] = fmaf(c1, sv, fmaf(cn[r >> 2][r & 3], -a.inv_d2, rnx));
-        }
+    // finishing registers 4 q .. 4 q + 3 is 20 operations, operation-major (idx = 4 op + i): op 0: the norm term, ops 1-3: own
+    // partial (still in registers) + the three others in a fixed order, op 4: x
+    float fsv[4], fcn[4];
+    auto xch_finish_op = [&](int q, int idx) __attribute__((always_inline)) {
+        const int i = idx & 3, op = idx >> 2, r = 4 * q + i;
+        if (op == 0) fcn[i] = fmaf(cn[i], -a.inv_d2, rnx);
+        else if (op == 1) fsv[i] = S[0][r] + part[0][i];
+        else if (op == 2) fsv[i] = fsv[i] + part[1][i];
+        else if (op == 3) fsv[i] = fsv[i] + part[2][i];
+        else xv[r] = fmaf(c1, fsv[i], fcn[i]);
     };
 
     double sum0 = 0.0, sum1 = 0.0, rowsum = 0.0;              // per-lane fp64 partials: Q sums by column set, this lane's row sum
 
-    q_f16x8 nab;                                              // k-step 0 operand of the NEXT interval's Gram (read at the end of this one)
-    auto gram_prefetch = [&](int b) {
-        wait_vmcnt_n(2 * (KB - 1));
-        nab = *reinterpret_cast<const q_f16x8*>(sm + xbuf_byte(b) + gram_off[0]);
-        __builtin_amdgcn_sched_barrier(0);
+    // Gram operand of slot t of the step in buffer b (pass t / NK, k-step t % NK).  Pass 0 reads a block for the first time:
+    // counted wait for its LDS-DMA (`slack` = DMA instructions issued after this step's)
+    auto gram_rd = [&](const Bases& B, int t, int slack) __attribute__((always_inline)) {
+        const int ks = t % NK;
+        if (t < NK && (ks & 1) == 0) wait_vmcnt_n(2 * (KB - 1 - (ks >> 1)) + slack);
+        ab[t % RING] = Q32_LDS(const q_f16x8, B.g[ks & 1] + 2048 * (ks >> 1));
     };
 
-    // First half of an interval: partial Gram of the step in buffer b, with the Q work of the PREVIOUS step (from xv; column
-    // set x_set, first point x_p0; pieces into E buffer ebuf) spread over the k-steps.  SLOW: masks of ragged edges
-    // (rows past n_rows, points past n_cols); a wave-uniform branch picks it per step.  `slack`: DMA instructions issued
-    // after this step's that may still be in flight.  WITH_E false: the prologue's Gram.
-    auto front = [&](auto slow_tag, auto with_e_tag, int b, int slack, int x_set, int x_p0, int ebuf) {
-        constexpr bool SLOW = decltype(slow_tag)::value, WITH_E = decltype(with_e_tag)::value;
-        const char* xs = sm + xbuf_byte(b);
-        constexpr int GD = NK < TVAE_Q32_GD ? NK : TVAE_Q32_GD;
-        q_f16x8 ab[NK];
-        auto rd = [&](int ks) {
-            if (WITH_E && ks == 0) { ab[0] = nab; return; }
-            wait_vmcnt_n(2 * (KB - 1 - (ks >> 1)) + slack);
-            ab[ks] = *reinterpret_cast<const q_f16x8*>(xs + gram_off[ks & 1] + 2048 * (ks >> 1));
-            __builtin_amdgcn_sched_barrier(0);      // keep the read HERE, ahead of the earlier k-steps' matrix instructions
-        };
-        float q[8];
-        auto e_slice = [&](int ks) {
-            // element el finishes in k-step el * (FIN + 1) / 8; sums, conversion and publication behind k-step FIN, with the
-            // matrix instructions of the remaining k-steps still to come
-            constexpr int FIN = NK > 2 ? NK - 3 : 0;
-#pragma unroll
-            for (int el = 0; el < 8; ++el) {
-                if (el * (FIN + 1) / 8 != ks) continue;
-                float qv = em1_split(-xv[el]).q;              // Q = x^2 r(x): second order, no cancellation
-                if constexpr (SLOW) {
-                    const bool ok = row_valid && (x_p0 + 16 * wp + 8 * (el >> 2) + 4 * h + (el & 3) < a.n_cols);
-                    qv = ok ? qv : 0.f;
-                }
-                q[el] = qv;
-            }
-            if (ks != FIN) return;
-            // this lane's eight entries belong to ONE row: their sum serves the Q sums and the row sum
-            const float es = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-            rowsum += (double)(x_set ? -es : es);
-            sum0 += (double)(x_set ? 0.f : es);
-            sum1 += (double)(x_set ? es : 0.f);
-            // prior columns enter the gradient with s_p = -1: folded into the fp16 scale
-            const float esc = x_set ? -SPLIT_E_SCALE : SPLIT_E_SCALE;
-            q_f16x8 ev;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) ev[r] = (_Float16)(q[r] * esc);
-            *reinterpret_cast<q_f16x8*>(sm + L::EBUF_OFF + ebuf * L::EBUF_ONE_B + (wp * 2 + wr) * 1024 + lane * 16) = ev;
-        };
-#pragma unroll
-        for (int ks = 0; ks < GD; ++ks) rd(ks);
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            if (ks + GD < NK) rd(ks + GD);
-#pragma unroll
-            for (int bq = 0; bq < 2; ++bq)
-                S[bq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[ks], zreg[bq][ks], ks == 0 ? zero16 : S[bq], 0, 0, 0);
-            if constexpr (WITH_E) e_slice(ks);
-        }
-    };
-
-    // gradient of the step in buffer b with the Q pieces of ebuf; a 32-feature block of the buffer is dead after its matrix
-    // instructions -> refilled in place with the same block of step Xn
-    constexpr int TD = KB < TVAE_Q32_TD ? KB : TVAE_Q32_TD;
+    // gradient operands: transposed reads of block blk (read rd = 2 kk + j), the Q pieces
     q_f16x8 Bq[2][2];                                         // [kk][actual rbk]
     q_s16x4 gh[KB][2][2];
-    auto grad_rd = [&](int xb0, int blk) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) gh[blk][kk][j] = tr_read(xb0 + 2048 * blk + tr_off[kk][j]);
+    auto grad_rd = [&](const Bases& B, int blk, int rd) __attribute__((always_inline)) {
+        gh[blk][rd >> 1][rd & 1] = tr_read(B.t[rd >> 1][rd & 1] + 2048 * blk);
     };
-    auto grad_fetch_x = [&](int b) {          // wave-private tile data: legal ahead of the barrier
-#pragma unroll
-        for (int blk = 0; blk < TD; ++blk) grad_rd((int)xbuf_byte(b), blk);
-        __builtin_amdgcn_sched_barrier(0);
+    constexpr int TDB = 1;                                    // feature blocks whose operands are read ahead of the barrier
+    constexpr int FH = 2 * KB;                                // gradient slot in which the second quad of partial sums is fetched
+    constexpr int FW0 = (20 + FH - 2) / (FH - 1), FW1 = (20 + 4 * KB - FH - 3) / (4 * KB - FH - 2);      // finishing operations per slot
+    static_assert(1 + 19 / FW0 < FH && FH + 2 + 19 / FW1 < 4 * KB, "finishing schedule");
+
+    // Q work of a step, as 40 single operations: element el = idx / 5, Horner step idx % 5 of
+    //     esc Q(x) = x^2 (k0 + k1 x + k2 x^2 + k3 x^3),   k = esc (1/2, 1/6, 1/24, 1/120),   esc = +-2^12
+    // (second order, no cancellation).  The kernel only runs when the device flag bounds every t of the call by 1/16
+    // (mmd.hip, QFlag): the next term, x^4 / 720, is below 4e-8 of Q there and 1e-13 of it at the t ~ 2 / D of the shapes
+    // that matter.  The fp16 scale of the Q pieces and the sign of prior columns (s_p = -1) ride in the coefficients, which
+    // are scalars picked per step: no multiply, no sign flip afterwards.
+    float pe[8];
+    float kq0 = 0.f, kq1 = 0.f, kq2 = 0.f, kq3 = 0.f;
+    // OPERATION-major order (idx = 8 op + el): neighbouring instructions belong to different elements -- a dependent vector
+    // instruction on a lone wave costs ~13 cycles against 8 for an independent one (the first slot version ran the five
+    // Horner steps of one element back to back: 84 cycles per slot instead of 40)
+    auto e_op = [&](int idx) __attribute__((always_inline)) {
+        const int el = idx % 8, op = idx / 8;
+        const float x = xv[el];
+        if (op == 0) pe[el] = fmaf(kq3, x, kq2);
+        else if (op == 1) pe[el] = fmaf(pe[el], x, kq1);
+        else if (op == 2) pe[el] = fmaf(pe[el], x, kq0);
+        else pe[el] = pe[el] * x;
     };
-    auto grad_fetch_e = [&](int ebuf) {
-        const char* eb = sm + L::EBUF_OFF + ebuf * L::EBUF_ONE_B + lane * 16;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int rbk = 0; rbk < 2; ++rbk) Bq[kk][rbk] = *reinterpret_cast<const q_f16x8*>(eb + (kk * 2 + rbk) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto grad_run = [&](int b, const Src& Xn) {
-        const int xb0 = (int)xbuf_byte(b);
-#pragma unroll
-        for (int blk = 0; blk < KB; ++blk) {
-            if (blk + TD < KB) grad_rd(xb0, blk + TD);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const q_f16x8 A = __builtin_bit_cast(q_f16x8, __builtin_shufflevector(gh[blk][kk][0], gh[blk][kk][1], 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                for (int rbk = 0; rbk < 2; ++rbk)
-                    acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bq[kk][rbk], acc[blk][rbk], 0, 0, 0);
-            }
-            // the matrix instructions of the block are issued (their operand reads have completed) before its refill
-            __builtin_amdgcn_sched_barrier(0);
-            dma_block(Xn, b, blk);
+
+    Src Xn2_c{};
+    int c_set_c = 0, c_p0_c = 0;
+
+    // ---- phase A: Gram of the step in buffer b  ||  Q of the previous step (column set x_set) into E buffer ebuf; partial sums
+    // of the Gram into exchange buffer xbuf.
+    // No edge masks in the loop: rows past n_rows only ever feed their own (discarded) gradient rows and are kept out of the
+    // sums by one select; the zero padding points past n_cols are taken out of the sums in closed form after the loop.
+    auto phase_a = [&](const Bases& Bg, const Bases& Bt, int x_set, int knext) __attribute__((always_inline)) {
+        constexpr bool WITH_E = true;
+        constexpr int slack = PF_SLACK;                       // behind this step's LDS-DMA: only the L2 prefetches of the last interval
+        constexpr int ESL = NS - 4;                           // Q operations spread over slots 0 .. ESL-1 (two per slot at D = 768)
+        constexpr int EW = (40 + ESL - 1) / ESL;
+        {
+            // sign by integer arithmetic on the (wave-uniform) set index: stays in scalar registers
+            const unsigned sbit = (unsigned)__builtin_amdgcn_readfirstlane(x_set) << 31;
+            kq0 = __uint_as_float(__float_as_uint(SPLIT_E_SCALE / 2.f) ^ sbit);
+            kq1 = __uint_as_float(__float_as_uint(SPLIT_E_SCALE / 6.f) ^ sbit);
+            kq2 = __uint_as_float(__float_as_uint(SPLIT_E_SCALE / 24.f) ^ sbit);
+            kq3 = __uint_as_float(__float_as_uint(SPLIT_E_SCALE / 120.f) ^ sbit);
         }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int lb = s < NK ? 1 : 0, ks = s % NK;
+            if (s == 0 || s == NK) {
+                // pin the gradient accumulators to their accumulator registers through the Gram: left alone, hipcc parks two
+                // of the blocks in vector registers for this phase and gives their registers to S (64 moves per step)
+#pragma unroll
+                for (int x = 0; x < KB; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) asm volatile("" : "+a"(acc[x][y]));
+            }
+            S[lb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[s % RING], zreg[lb][ks], ks == 0 ? zero16 : S[lb], 0, 0, 0);
+            Q32_PIN();
+#if TVAE_Q32_DIAG != 2
+            if (s + GD < NS) gram_rd(Bg, s + GD, slack);
+#endif
+            if constexpr (WITH_E && TVAE_Q32_DIAG != 1) {
+                if (s < ESL) {
+#pragma unroll
+                    for (int i = 0; i < EW; ++i)
+                        if (EW * s + i < 40) e_op(EW * s + i);
+                } else if (s == ESL) {
+                    // this lane's eight entries belong to ONE row: their sum serves the Q sums and the row sum.  pe = s_p 2^12 Q
+                    float es = ((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7]));
+                    es = row_valid ? es * (1.f / SPLIT_E_SCALE) : 0.f;         // a power of two: exact
+                    rowsum += (double)es;
+                    // |es| is the (non-negative) Q sum of the step's set; the other set's sum gets an exact zero
+                    sum0 += (double)__uint_as_float(__float_as_uint(es) & (x_set ? 0u : 0x7fffffffu));
+                    sum1 += (double)__uint_as_float(__float_as_uint(es) & (x_set ? 0x7fffffffu : 0u));
+                } else if (s == ESL + 1) {
+                    q_f16x8 ev;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) ev[r] = (_Float16)pe[r];
+                    Q32_LDS(q_f16x8, Bt.ew) = ev;
+                }
+            }
+            // the foreign row block is complete after slot NK - 1: its four stores two slots later (matrix-pipe latency)
+#if TVAE_Q32_DIAG != 3
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (s == (NK + 2 + i < NS - 1 ? NK + 2 + i : NS - 1)) xch_store(Bg, i >> 1, i & 1);
+#endif
+            if constexpr (WITH_E) {
+                // the gradient's first operand reads (wave-private step data: legal ahead of the barrier), two per slot
+#pragma unroll
+                for (int i = 0; i < 4 * TDB; ++i)
+                    if (s == (NS - 2 * TDB + i / 2 > 0 ? NS - 2 * TDB + i / 2 : 0)) grad_rd(Bt, i >> 2, i & 3);
+            }
+            Q32_PIN();
+        }
+        if constexpr (WITH_E) {
+            // the next interval's scalars, in the shadow of the last matrix instruction's latency
+            step_meta(sb + knext, c_set_c, c_p0_c);
+            Xn2_c = step_src(sb + knext + 2);
+            Q32_PIN();
+        }
+        xch_store(Bg, 2, 0);
+        xch_store(Bg, 2, 1);
+    };
+
+    // ---- phase C: gradient of the step in buffer b (Q pieces of ebuf; each 32-feature block refilled in place with step Xn
+    // behind its matrix instructions)  ||  reduction of the next step's partial sums (exchange buffer xbuf, norms nbuf)
+    auto phase_c = [&](const Bases& Bt, const Bases& Bg, int b, const Src& Xn, const Src& Xpf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int rbk = 0; rbk < 2; ++rbk) Bq[kk][rbk] = Q32_LDS(const q_f16x8, Bt.er + (kk * 2 + rbk) * 1024);
+        xch_fetch(Bg, 0);
+        Q32_PIN();
+        stage_norms(Xn, b);
+        Q32_PIN();
+#pragma unroll
+        for (int s = 0; s < 4 * KB; ++s) {
+            const int blk = s >> 2, kk = (s >> 1) & 1, rbk = s & 1;
+            const q_f16x8 A = __builtin_bit_cast(q_f16x8, __builtin_shufflevector(gh[blk][kk][0], gh[blk][kk][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bq[kk][rbk], acc[blk][rbk], 0, 0, 0);
+            Q32_PIN();
+            if (blk + TDB < KB) grad_rd(Bt, blk + TDB, s & 3);
+            // block blk - 1 is dead (its matrix instructions are issued, their operand reads have completed): refill it
+            if ((s & 3) == 0 && blk >= 1) dma_block(Xn, b, blk - 1);
+            // the 20 finishing operations of registers 0-3 in slots 1 .. H-1, the second quad's partial sums fetched in slot H,
+            // its 20 operations in slots H+2 .. (two per slot at D = 768)
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                if (s == 1 + i / FW0) xch_finish_op(0, i);
+                if (s == FH + 2 + i / FW1) xch_finish_op(1, i);
+            }
+            if (s == FH) xch_fetch(Bg, 1);
+            Q32_PIN();
+        }
+        dma_block(Xn, b, KB - 1);
+        // slots 0 .. GD-1 of the next interval's Gram: the step just refilled into this buffer
+#pragma unroll
+        for (int t = 0; t < GD; ++t) gram_rd(Bt, t, 0);
+        Q32_PIN();
+        l2_prefetch(Xpf);
+        Q32_PIN();
     };
 
 #ifdef TVAE_PHASE_TIMING
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
 #endif
-    Src Xn2_c{};
-    int c_set_c = 0, c_p0_c = 0;
-    bool slow_c = true;
-    auto interval = [&](int k) {
+    auto interval = [&](int k) __attribute__((always_inline)) {
         PHASE_MARK(5);
         const int cur = k & 1, nxt = cur ^ 1;
-        // this interval's scalars were worked out at the end of the previous one, behind its last matrix instructions
+        // this interval's scalars were worked out in the previous one
         const Src Xn2 = Xn2_c;
-        const int c_set = c_set_c, c_p0 = c_p0_c;
-        // Gram of the next step  ||  Q of this one (from xv, left by the previous interval)
-        if (slow_c) front(std::true_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);   // wave-uniform
-        else front(std::false_type{}, std::true_type{}, nxt, 0, c_set, c_p0, cur);
+        const int c_set = c_set_c;
+        const Bases Bn = gram_bases(nxt), Bc = grad_bases(cur);
+        phase_a(Bn, Bc, c_set, k + 1);
         PHASE_MARK(0);
-        // the barrier needs the WRITES (Q piece, partials) retired, not the gradient's operand reads: LDS operations retire
-        // in order, so with the reads issued behind the writes a counted wait leaves them in flight across the barrier
-        xch_write(nxt);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        grad_fetch_x(cur);
-        {
-            constexpr int NRD = TD * 4;
-            static_assert(NRD <= 15, "lgkmcnt is a 4-bit counter");
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
-        }
+        // the barrier needs the WRITES (Q piece, partial sums) retired: LDS operations retire in order, the gradient's
+        // operand reads were issued before the last stores
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PHASE_MARK(1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         PHASE_MARK(2);
-        // gradient of this step (+ refill with step k + 2)  ||  reduction of the next step's partials
-        grad_fetch_e(cur);
-        stage_norms(Xn2, cur);
-        xch_fetch(nxt, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        PHASE_MARK(3);
-        grad_run(cur, Xn2);
-        xch_finish();
-        step_meta(sb + k + 1, c_set_c, c_p0_c);
-        Xn2_c = step_src(sb + k + 3);
-        slow_c = any_invalid || c_p0_c + P > a.n_cols;
-        gram_prefetch(cur);                   // the next interval's Gram: the step just refilled into this buffer
+        phase_c(Bc, Bn, cur, Xn2, step_src(sb + k + 2 + PFD));
         PHASE_MARK(4);
     };
 
     if (nsteps > 0) {
-        // ---- prologue: steps sb, sb + 1 in flight; Gram and exchange of the first one ----
+        // ---- prologue = interval -1 of the SAME loop body (one instance of the code: a second, E-less instance of phase A got
+        // its own accumulator registers and the loop's then time-shared theirs with two gradient blocks, 64 register moves
+        // per step).  Step sb is loaded into BOTH buffers: buffer 0 for the Gram, buffer 1 as the "previous step" whose
+        // gradient interval -1 forms from Q = 0 (xv = 0: every Q, sum and E piece of it is an exact zero; a finite step
+        // times zero adds exact zeros to the accumulators); its refill brings step sb + 1 into buffer 1.
         {
-            const Src X0 = step_src(sb), X1 = step_src(sb + 1);
+            const Src X0 = step_src(sb);
+            stage_norms(X0, 1);
+#pragma unroll
+            for (int s = 0; s < KB; ++s) dma_block(X0, 1, s);
             stage_norms(X0, 0);
 #pragma unroll
             for (int s = 0; s < KB; ++s) dma_block(X0, 0, s);
-            stage_norms(X1, 1);
 #pragma unroll
-            for (int s = 0; s < KB; ++s) dma_block(X1, 1, s);
-            front(std::false_type{}, std::false_type{}, 0, 1 + 2 * KB, 0, 0, 0);
-            xch_write(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            xch_fetch(0, 0);
-            xch_finish();
-            gram_prefetch(1);
-            step_meta(sb, c_set_c, c_p0_c);
-            Xn2_c = step_src(sb + 2);
-            slow_c = any_invalid || c_p0_c + P > a.n_cols;
+            for (int r = 0; r < 8; ++r) xv[r] = 0.f;
+            {
+                const Bases B0 = grad_bases(0);
+#pragma unroll
+                for (int t = 0; t < GD; ++t) gram_rd(B0, t, 0);
+            }
+            wait_vmcnt<0>();                                  // buffer 1 is read transposed at the end of phase A without a counted wait
+            Q32_PIN();
+            c_set_c = 0; c_p0_c = 0;
+            Xn2_c = step_src(sb + 1);
         }
-        for (int k = 0; k < nsteps; ++k) interval(k);
+        for (int k = -1; k < nsteps; ++k) interval(k);
+        // The zero padding points of this workgroup's column range (points [n_cols, n_pad) of either set) went through the
+        // loop like any other: x = -|z_i|^2 / D^2 exactly (zero Gram, zero norm), the same Q for every one of them, nothing
+        // into the gradient (x_p = 0).  Take them out of the sums: this lane's row saw (its half of) the padding points of
+        // each 16-point half it finishes -- count them per set and subtract count * Q(x).
+        {
+            int npad[2] = {0, 0};
+#pragma unroll 1
+            for (int v = sb; v < se; ++v) {
+                int set, p0;
+                step_meta(v, set, p0);
+                if (p0 + P <= a.n_cols) continue;
+#pragma unroll
+                for (int el = 0; el < 8; ++el) npad[set] += (p0 + 16 * wp + 8 * (el >> 2) + 4 * h + (el & 3) >= a.n_cols) ? 1 : 0;
+            }
+            if ((npad[0] | npad[1]) != 0 && row_valid) {
+                const double qp = (double)em1_split(-rnx).q;
+                sum0 -= npad[0] * qp;
+                sum1 -= npad[1] * qp;
+                rowsum -= (npad[0] - npad[1]) * qp;
+            }
+        }
     }
     wait_vmcnt<0>();
+    asm volatile("" : "+v"(pf_sink));          // the prefetch sink stays allocated until every load has returned
 #ifdef TVAE_PHASE_TIMING
     if (blockIdx.x == 0 && lane == 0 && nsteps > 0)
         printf("wave %d steps %d: front %llu  xch write %llu  barrier %llu  fetch %llu  grad %llu  top %llu (cycles per step)\n", wave,
