@@ -885,6 +885,7 @@ struct Plan {
     int narrow64;           // 1: mmd_narrow_kernel (padded dimension <= 80): 64 rows per single-wave workgroup
     int n16;                // 1 (with split, without bf16_tiles): mmd_n16_kernel, narrow latents on the fp16 matrix cores
     int qform;              // 1 (with pipe and split): Q-form gradient, linear part in closed form (see QFlag)
+    int qsum;               // 1 (split pipelined sum-only launches): the device flag also picks the one-product sum kernel (mmd_q32.hip)
     int ldq;                // row stride of M2 and P (D + 1 columns, padded)
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
     int sp_major;     // 1: split-major workgroup order (see make_plan)
@@ -1075,7 +1076,8 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
         if (g2 > gs_floats) gs_floats = g2;
     }
     p->off_gslab = take(gs_floats * 4);
-    p->off_qflag = take(p->qform ? 256 : 0);
+    p->qsum = (kQForm && p->split && p->pipe_sum) ? 1 : 0;
+    p->off_qflag = take((p->qform || p->qsum) ? 256 : 0);
     p->bytes = off;
     return true;
 }
@@ -1278,15 +1280,17 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     QFlag* qflag = nullptr;
     float* m3 = nullptr;
     float* pmat = nullptr;
-    if (p.qform) {
+    if (p.qform || p.qsum) {
         qflag = reinterpret_cast<QFlag*>(ws + p.off_qflag);
+        hipLaunchKernelGGL(mmd_qflag_kernel, dim3(1), dim3(1024), 0, s, (const float*)zn, (const float*)yn, (int)n_total, (int)D, qflag);
+        TVAE_CHECK_HIP(hipGetLastError());
+    }
+    if (p.qform) {
         m3 = reinterpret_cast<float*>(ws + p.off_m3);
         pmat = reinterpret_cast<float*>(ws + p.off_p);
         float* m2z = reinterpret_cast<float*>(ws + p.off_m2);
         float* m2y = m2z + (long long)D * p.ldq;
         float* gslab = reinterpret_cast<float*>(ws + p.off_gslab);
-        hipLaunchKernelGGL(mmd_qflag_kernel, dim3(1), dim3(1024), 0, s, (const float*)zn, (const float*)yn, (int)n_total, (int)D, qflag);
-        TVAE_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(mmd_m3_kernel, dim3((p.DPAD + 255) / 256), dim3(256), 0, s, (const float*)colpart3, nwaves, p.DPAD, m3);
         TVAE_CHECK_HIP(hipGetLastError());
         GemmDesc g{};
@@ -1370,7 +1374,7 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     f.d_z = d_z;
     f.split_amax = split_amax;
     f.zn = zn; f.yn = yn; f.n_total = (int)n_total; f.dots = dots; f.ndots = ndots;
-    f.qflag = qflag; f.m3 = m3; f.P = pmat; f.ldP = p.ldq;
+    f.qflag = p.qform ? qflag : nullptr; f.m3 = m3; f.P = pmat; f.ldP = p.ldq;
     long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
     if (fb > 4096) fb = 4096;
     if (fb < 1) fb = 1;

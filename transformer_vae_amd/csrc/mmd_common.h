@@ -164,6 +164,7 @@ int launch_mmd_bf16(bool grad, bool split, int kb, int rt, const MmdArgs& a, int
 int launch_mmd_pipe(bool grad, bool split, int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 // Q-form member of the split gradient launch pair: one fp16 product, 32-point steps, 32x32x16 everywhere (mmd_q32.hip); kb = 2..6
 int launch_mmd_q32(int kb, const MmdArgs& a, int nblocks, hipStream_t s);
+int launch_mmd_q32_sum(int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 // fp32 kernel for narrow latents, 64 rows per single-wave workgroup (mmd_narrow.hip); nb = padded dimension / 16 (1..5)
 int launch_mmd_narrow(bool grad, int nb, const MmdArgs& a, int nblocks, hipStream_t s);
 // split-fp16 kernel for narrow latents, one wave per workgroup (mmd_n16.hip); kbn = padded dimension / 32 (1..6).

@@ -673,6 +673,10 @@ __global__ __launch_bounds__(256, 1) void mmd_pipe_kernel(MmdArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 template <int KB, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void mmd_pipe_sum_kernel(MmdArgs a) {
+    // split mode with the device flag on: the one-product kernel of the launch pair does the work (mmd_q32.hip)
+    if constexpr (SPLIT && TVAE_Q32) {
+        if (a.qflag != nullptr && __builtin_amdgcn_readfirstlane((int)*a.qflag) != 0) return;
+    }
     // With the two-product Gram (mmd_common.h) a sum-only launch never reads the lo copy of the columns, so split mode
     // takes the bf16 instantiation's LDS layout and 32-point steps (two point tiles of the hi copy per 2 KiB block)
     // with fp16 arithmetic and the row side's second product: half the barriers, exchanges and scalar bookkeeping per
@@ -1002,6 +1006,9 @@ int launch_pipe_sum(const MmdArgs& a, int nblocks, hipStream_t s) {
     }));
     hipLaunchKernelGGL((mmd_pipe_sum_kernel<KB, SPLIT>), dim3(nblocks), dim3(256), lds_bytes, s, a);
     TVAE_CHECK_HIP(hipGetLastError());
+    if constexpr (SPLIT && TVAE_Q32) {
+        if (a.qflag != nullptr) return launch_mmd_q32_sum(KB, a, nblocks, s);      // the pair: exactly one of the two does the work
+    }
     return TVAE_OK;
 }
 

@@ -57,6 +57,7 @@ struct Q32Lds {
 #define TVAE_Q32_DIAG 0       // timing diagnostics (results are wrong): 1 no Q work, 2 no Gram operand reads, 3 no foreign stores, 4 same tile every step
 #endif
 
+
 __device__ __forceinline__ int q32_swz(int q) { return (2 * (q & 1)) ^ ((q >> 1) & 1) ^ (3 * ((q >> 2) & 1)); }
 
 template <int KB>
@@ -573,6 +574,316 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Sum-only companion (the y-rows launch of a gradient call: y-y, each unordered pair of 64-point blocks once when the row
+// range allows; both problems of a call without gradient), the Q-form member of ITS launch pair: same one-product 32x32x16
+// Gram, same LDS image, exchange and slot discipline as mmd_q32_kernel; no gradient phase, so an interval is
+//
+//     Gram(k+1), two passes  ||  finish the partial sums of step k, Q, sums        -> stores of S'(k+1) -> ONE barrier
+//
+// Two step buffers: the one under the Gram is refilled block by block behind pass 1 with step k + 3 (the other holds
+// step k + 2), so every LDS-DMA has more than an interval to land.  Norms in a ring of four.  The symmetric enumeration,
+// column splits and outputs are those of mmd_pipe_sum_kernel (mmd_pipe.hip).
+// ------------------------------------------------------------------------------------------------------------------
+template <int KB>
+struct Q32SumLds {
+    static constexpr int SLICE_B = KB * 2048;
+    static constexpr int XBUF_B = 4 * SLICE_B;
+    static constexpr int NORM_OFF = 2 * XBUF_B;               // [4 ring][4 waves][64] floats
+    static constexpr int XCH_OFF = NORM_OFF + 4 * 4 * 64 * 4;
+    static constexpr int XCH_ONE_B = 4 * 3 * 2 * 1024;
+    static constexpr int BYTES = XCH_OFF + 2 * XCH_ONE_B;
+    static_assert(BYTES <= 160 * 1024, "q32 sum kernel exceeds the 160 KiB LDS");
+};
+
+template <int KB>
+__global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
+    if (__builtin_amdgcn_readfirstlane((int)*a.qflag) == 0) return;
+    using L = Q32SumLds<KB>;
+    constexpr int P = 32, SW = 32 * KB, DPAD = 4 * SW, NK = 2 * KB, NS = 2 * NK, SPB = 64 / P;
+    constexpr int GD = 3, RING = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sm = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wp = wave & 1;
+    const int n32 = lane & 31, h = lane >> 5;
+    const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int lds0 = (int)smem_byte;
+
+    const int per_problem = a.row_blocks * a.col_splits;
+    const int problem = a.problem_base + (int)blockIdx.x / per_problem;
+    const int rem = (int)blockIdx.x - (problem - a.problem_base) * per_problem;
+    const int rb = a.sp_major ? rem % a.row_blocks : rem / a.col_splits;
+    const int sp = a.sp_major ? rem / a.row_blocks : rem - rb * a.col_splits;
+    const int i0 = rb * 64;
+    const long long bid = (long long)a.sums_base + blockIdx.x;
+
+    const _Float16* rows = reinterpret_cast<const _Float16*>(a.cols[problem]) + (long long)a.row_offset * DPAD;
+    const float* rnorm = a.cnorm[problem] + a.row_offset;
+    q_f16x8 zreg[2][NK];                                      // rotated block order: see mmd_q32_kernel
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int row = i0 + 32 * (b ^ wr) + n32;
+        const _Float16* zp = rows + (long long)row * DPAD + wave * SW + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            if (row < a.n_rows) zreg[b][ks] = *reinterpret_cast<const q_f16x8*>(zp + 16 * ks);
+            else zreg[b][ks] = q_f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    const int my_row = i0 + 32 * wr + n32;
+    const bool row_valid = my_row < a.n_rows;
+    const SplitScales ss = split_scales(*a.split_amax);
+    const float c1 = 2.f * ss.inv_s2 * a.inv_d2;
+    float rnx = row_valid ? -rnorm[my_row] * a.inv_d2 : 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) asm volatile("" : "+v"(zreg[b][ks]));
+    asm volatile("" : "+v"(rnx));
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    asm volatile("" : "+v"(zero16));
+
+    // steps of 32 points (mmd_pipe_sum_kernel: problem 0 = z rows against both sets; problem 1 = y rows against the priors,
+    // all of them or, sym, each unordered pair of 64-point blocks once with weight 2 off the diagonal)
+    const int nS = a.tiles_per_set / 2;
+    const int nJ = nS / SPB;
+    const bool sym = problem == 1 && a.sym;
+    const int blkI = (a.row_offset >> 6) + rb;
+    const int jlo = (int)((long long)sp * nJ / a.col_splits), jhi = (int)((long long)(sp + 1) * nJ / a.col_splits);
+    const int aend = blkI < jhi ? blkI : jhi;
+    const int ja0 = jlo + ((jlo ^ (blkI + 1)) & 1);
+    const int nA = aend > ja0 ? (aend - ja0 + 1) >> 1 : 0;
+    const int nB = (blkI >= jlo && blkI < jhi) ? 1 : 0;
+    const int cbeg = blkI + 1 > jlo ? blkI + 1 : jlo;
+    const int jc0 = cbeg + ((cbeg ^ blkI) & 1);
+    const int nC = jhi > jc0 ? (jhi - jc0 + 1) >> 1 : 0;
+    const long long total = problem == 0 ? 2ll * nS : (long long)nS;
+    const long long base = problem == 0 ? 0 : nS;
+    const int sb = sym ? 0 : (int)(base + sp * total / a.col_splits);
+    const int se = sym ? (nA + nB + nC) * SPB : (int)(base + (sp + 1) * total / a.col_splits);
+    const int nsteps = se - sb;
+
+    struct Meta { int set, p0; float w; };
+    auto step_meta = [&](int v) __attribute__((always_inline)) -> Meta {
+        const int u = v < se ? v : se - 1;
+        if (sym) {
+            const int blk = u / SPB, sub = u - blk * SPB;
+            const int J = blk < nA ? ja0 + 2 * blk : (blk < nA + nB ? blkI : jc0 + 2 * (blk - nA - nB));
+            return Meta{1, J * 64 + sub * P, J != blkI ? 2.f : 1.f};
+        }
+        const int set = u >= nS ? 1 : 0;
+        return Meta{set, (u - (set ? nS : 0)) * P, 1.f};
+    };
+    struct Src { const _Float16* x; const float* nrm; };
+    const _Float16* const cbase0 = reinterpret_cast<const _Float16*>(a.cols[0]) + wave * SW;
+    const _Float16* const cbase1 = reinterpret_cast<const _Float16*>(a.cols[1]) + wave * SW;
+    const float* const nbase0 = a.cnorm[0];
+    const float* const nbase1 = a.cnorm[1];
+    auto step_src = [&](int v) __attribute__((always_inline)) -> Src {
+        const Meta m = step_meta(v);
+        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(m.p0) * (unsigned)DPAD;
+        return Src{(m.set ? cbase1 : cbase0) + off, (m.set ? nbase1 : nbase0) + m.p0};
+    };
+
+    unsigned dma_voff0, dma_voff1;
+    {
+        const int r = lane >> 2, pos = lane & 3;
+        dma_voff0 = (unsigned)(r * DPAD + 8 * (pos ^ q32_swz(r >> 2))) * 2u;
+        dma_voff1 = (unsigned)((16 + r) * DPAD + 8 * (pos ^ q32_swz(4 + (r >> 2)))) * 2u - 1024u;
+    }
+    int gram_off[2];
+    {
+        const int pa = n32 ^ (16 * wp);
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+            gram_off[par] = 1024 * (pa >> 4) + 64 * (pa & 15) + 16 * ((2 * par + h) ^ q32_swz(pa >> 2));
+    }
+    auto xbuf_byte = [&](int b) __attribute__((always_inline)) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
+    auto stage_norms = [&](const Src& X, int ring) __attribute__((always_inline)) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(L::NORM_OFF + (ring * 4 + wave) * 64 * 4));
+        dma4(uniform_ptr(X.nrm), (unsigned)lane * 4u, dst);
+    };
+    auto dma_block = [&](const Src& X, int b, int s) __attribute__((always_inline)) {
+        dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff0, dma_voff1, smem_byte + xbuf_byte(b) + 2048u * s);
+    };
+    int xw_off[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int b = c < 2 ? 1 : 0, hf = c == 0 ? 0 : 1;
+        const int owner = 2 * (b ^ wr) + (hf ^ wp);
+        xw_off[c] = lds0 + L::XCH_OFF + lane * 16 + ((owner * 3 + ((wave - owner - 1) & 3)) * 2) * 1024;
+    }
+    const int xr_off = lds0 + L::XCH_OFF + lane * 16 + wave * 3 * 2 * 1024;
+    const int nr_off = lds0 + L::NORM_OFF + (wave * 64 + 16 * wp + 4 * h) * 4;
+
+    f32x16 S[2];
+    q_f16x8 ab[RING];
+    float xv[8], fsv[8], fcn[8], pe[8];
+    f32x4 part[2][3], cn[2];
+    double sum0 = 0.0, sum1 = 0.0;
+
+    // one interval: Gram of the step in buffer b (tile k + 1), refilled behind pass 1 with step Xr (norms into ring slot
+    // ring_r); the partial sums of step k (exchange buffer xb_rd, norms in ring slot ring_e, meta m) are finished and summed
+    // between the matrix instructions; the partial sums of the Gram go to exchange buffer xb_wr.
+    // idx list of the vector work, operation-major over the eight entries of a lane:
+    //   [0, 40)  finishing (op 0: norm term; 1-3: own + three remote partials; 4: x)      [40, 80)  Q (five Horner steps)
+    auto v_op = [&](int idx) __attribute__((always_inline)) {
+        if (idx < 40) {
+            const int r = idx & 7, op = idx >> 3;
+            if (op == 0) fcn[r] = fmaf(cn[r >> 2][r & 3], -a.inv_d2, rnx);
+            else if (op == 1) fsv[r] = S[0][r] + part[r >> 2][0][r & 3];
+            else if (op == 2) fsv[r] = fsv[r] + part[r >> 2][1][r & 3];
+            else if (op == 3) fsv[r] = fsv[r] + part[r >> 2][2][r & 3];
+            else xv[r] = fmaf(c1, fsv[r], fcn[r]);
+        } else {
+            const int el = (idx - 40) & 7, op = (idx - 40) >> 3;
+            const float x = xv[el];
+            if (op == 0) pe[el] = fmaf(1.f / 120.f, x, 1.f / 24.f);
+            else if (op == 1) pe[el] = fmaf(pe[el], x, 1.f / 6.f);
+            else if (op == 2) pe[el] = fmaf(pe[el], x, 0.5f);
+            else pe[el] = pe[el] * x;
+        }
+    };
+    // the own partial S[0][0..7] of step k is consumed by op 1 above; the Gram of step k + 1 overwrites S[0] in pass 1 (slots
+    // NK ..): op 1 has to be placed before slot NK -- the list puts idx 8 .. 15 into slots <= 5
+    constexpr int V0 = 0;                                     // first slot with vector work (the partial sums' LDS round trip before it)
+    constexpr int VSL = NS - 3 - V0;                          // vector work spread over slots V0 .. V0 + VSL - 1
+    constexpr int VW = (80 + VSL - 1) / VSL;
+    static_assert(V0 + (15 / VW) < NK, "the own partial sums are read before pass 1 overwrites them");
+    auto interval = [&](int b, const Src& Xr, int ring_r, int xb_rd, int xb_wr, int ring_e, const Meta& m, bool with_e, int slack) __attribute__((always_inline)) {
+        const int gb0 = lds0 + (int)xbuf_byte(b);
+        int gbase[2] = {gb0 + gram_off[0], gb0 + gram_off[1]};
+        asm volatile("" : "+v"(gbase[0]), "+v"(gbase[1]));
+        int xw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xw[c] = xw_off[c] + xb_wr * L::XCH_ONE_B; asm volatile("" : "+v"(xw[c])); }
+        auto gram_rd = [&](int t) __attribute__((always_inline)) {
+            const int ks = t % NK;
+            if (t < NK && (ks & 1) == 0) wait_vmcnt_n(2 * (KB - 1 - (ks >> 1)) + slack);
+            ab[t % RING] = Q32_LDS(const q_f16x8, gbase[ks & 1] + 2048 * (ks >> 1));
+        };
+        {
+            const int xr = xr_off + xb_rd * L::XCH_ONE_B, nr = nr_off + ring_e * 4 * 64 * 4;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w) part[q][w] = Q32_LDS(const f32x4, xr + (w * 2 + q) * 1024);
+                cn[q] = Q32_LDS(const f32x4, nr + 8 * q * 4);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < GD; ++t) gram_rd(t);
+        Q32_PIN();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int lb = s < NK ? 1 : 0, ks = s % NK;
+            S[lb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[s % RING], zreg[lb][ks], ks == 0 ? zero16 : S[lb], 0, 0, 0);
+            Q32_PIN();
+            if (s + GD < NS) gram_rd(s + GD);
+            if (s == NK - 1) stage_norms(Xr, ring_r);      // behind pass 0's last counted wait: the counts above stay exact
+            if (s >= V0 && s < V0 + VSL) {
+#pragma unroll
+                for (int i = 0; i < VW; ++i)
+                    if (VW * (s - V0) + i < 80) v_op(VW * (s - V0) + i);
+            } else if (s == V0 + VSL) {
+                float es = ((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7]));
+                es = (row_valid && with_e) ? es * m.w : 0.f;
+                sum0 += (double)(m.set ? 0.f : es);
+                sum1 += (double)(m.set ? es : 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (s == (NK + 2 + i < NS - 1 ? NK + 2 + i : NS - 1))
+                    Q32_LDS(f32x4, xw[i >> 1] + (i & 1) * 1024) = f32x4{S[1][8 * (i >> 1) + 4 * (i & 1)], S[1][8 * (i >> 1) + 4 * (i & 1) + 1],
+                                                                          S[1][8 * (i >> 1) + 4 * (i & 1) + 2], S[1][8 * (i >> 1) + 4 * (i & 1) + 3]};
+            // pass 1 has read both k-steps of block blk: refill it with the same block of step Xr
+            if (s >= NK && (ks & 1) == 1) dma_block(Xr, b, ks >> 1);
+            Q32_PIN();
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            Q32_LDS(f32x4, xw[2] + q * 1024) = f32x4{S[0][8 + 4 * q], S[0][8 + 4 * q + 1], S[0][8 + 4 * q + 2], S[0][8 + 4 * q + 3]};
+    };
+
+    if (nsteps > 0) {
+        // prologue: steps sb, sb + 1 into the two buffers (norm ring slots 0, 1), then interval "-1": Gram of step sb with
+        // nothing to finish (with_e false: its sums are discarded; the registers it reads hold zeros)
+        const Src X0 = step_src(sb), X1 = step_src(sb + 1);
+        stage_norms(X0, 0);
+#pragma unroll
+        for (int s = 0; s < KB; ++s) dma_block(X0, 0, s);
+        stage_norms(X1, 1);
+#pragma unroll
+        for (int s = 0; s < KB; ++s) dma_block(X1, 1, s);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { xv[r] = 0.f; pe[r] = 0.f; fsv[r] = 0.f; fcn[r] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; }
+        wait_vmcnt<0>();
+        __syncthreads();
+        // k = -1: buffer 0 holds step sb; its refill is step sb + 2 (ring slot 2)
+        // interval k: Gram of step k + 1 in buffer (k + 1) & 1, refill with step k + 3, finishing step k
+        for (int k = -1; k < nsteps; ++k) {
+            const int b = (k + 1) & 1;
+            const Src Xr = step_src(sb + k + 3);
+            const Meta m = step_meta(sb + (k < 0 ? 0 : k));
+            // DMA in flight on entry beside this step's own (older): the norms + 2 KB pieces of the step in the other buffer
+            interval(b, Xr, (k + 3) & 3, k & 1, (k + 1) & 1, k & 3, m, k >= 0, 1 + 2 * KB);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // the zero padding points of this workgroup's column range: out of the sums in closed form (see mmd_q32_kernel)
+        {
+            float npad[2] = {0.f, 0.f};
+#pragma unroll 1
+            for (int v = sb; v < se; ++v) {
+                const Meta m = step_meta(v);
+                if (m.p0 + P <= a.n_cols) continue;
+#pragma unroll
+                for (int el = 0; el < 8; ++el) npad[m.set] += (m.p0 + 16 * wp + 8 * (el >> 2) + 4 * h + (el & 3) >= a.n_cols) ? m.w : 0.f;
+            }
+            if ((npad[0] != 0.f || npad[1] != 0.f) && row_valid) {
+                const float x = rnx;
+                float p = fmaf(1.f / 120.f, x, 1.f / 24.f);
+                p = fmaf(p, x, 1.f / 6.f);
+                p = fmaf(p, x, 0.5f);
+                const double qp = (double)((p * x) * x);
+                sum0 -= (double)npad[0] * qp;
+                sum1 -= (double)npad[1] * qp;
+            }
+        }
+    }
+    wait_vmcnt<0>();
+
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(sm + L::XCH_OFF);
+    const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
+    if (lane == 0) { red[wave * 2 + 0] = w0; red[wave * 2 + 1] = w1; }
+    __syncthreads();
+    if (tid == 0) {
+        a.wg_sums[2 * bid + 0] = (red[0] + red[2]) + (red[4] + red[6]);
+        a.wg_sums[2 * bid + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+
+template <int KB>
+int launch_q32_sum(const MmdArgs& a, int nblocks, hipStream_t s) {
+    constexpr int lds_bytes = Q32SumLds<KB>::BYTES;
+    static PerDeviceOnce once;
+    TVAE_CHECK_HIP(per_device_once(once, [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_q32_sum_kernel<KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   lds_bytes);
+    }));
+    hipLaunchKernelGGL((mmd_q32_sum_kernel<KB>), dim3(nblocks), dim3(256), lds_bytes, s, a);
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
 template <int KB>
 int launch_q32(const MmdArgs& a, int nblocks, hipStream_t s) {
     constexpr int lds_bytes = Q32Lds<KB>::BYTES;
@@ -598,6 +909,18 @@ int launch_mmd_q32(int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
         case 6: return launch_q32<6>(a, nblocks, s);
     }
     return fail(TVAE_ERR_ARG, "mmd: no q32 kernel for %d feature blocks", kb);
+}
+
+// the Q-form member of the sum-only launch pair
+int launch_mmd_q32_sum(int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
+    switch (kb) {
+        case 2: return launch_q32_sum<2>(a, nblocks, s);
+        case 3: return launch_q32_sum<3>(a, nblocks, s);
+        case 4: return launch_q32_sum<4>(a, nblocks, s);
+        case 5: return launch_q32_sum<5>(a, nblocks, s);
+        case 6: return launch_q32_sum<6>(a, nblocks, s);
+    }
+    return fail(TVAE_ERR_ARG, "mmd: no q32 sum kernel for %d feature blocks", kb);
 }
 
 }  // namespace tvae
