@@ -164,6 +164,38 @@ int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all,
                      void* d_z, double grad_scale,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same evaluation cut into three stages, for a GLOBAL batch whose rows are sharded over R processes (one per GPU):
+ * what `EncoderDecoderVAE._regularliser_loss` (autoencoders.py:128-136) computes when the batch it is given is the
+ * concatenation of every rank's rows -- the reference itself has no collective (under DDP each rank regularises its own
+ * rows).  No rank touches another rank's rows before the last stage, so the O(N D) preparation and the O(N D^2)
+ * closed-form products shrink with R like the tile work does, and what travels is the fp16 image (half the bytes of the
+ * fp32 latents).  Every rank passes the same n_total, n_rows (equal row counts), D, dtype and want_grad, its own
+ * row_offset = rank * n_rows, its own rows z_loc / y_loc (n_rows, D), and ONE workspace of
+ * tvae_mmd_workspace_bytes_for() bytes that lives across the three calls.  Between the calls the caller moves the
+ * regions tvae_mmd_shard_layout names (collectives are the caller's: RCCL in distributed.py):
+ *     tvae_mmd_stats_local   -> rec_a: SUM over ranks (its max |value| word: MAX)
+ *     tvae_mmd_prep_local    -> image rows and norms of the own rows: ALL-GATHER in rank order;
+ *                               rec_b_local: SUM over ranks into rec_b (its max-norm word: MAX); gram: SUM over ranks
+ *     tvae_mmd_tiles         -> sums3 / loss / d_z of the own rows as tvae_mmd_fwd_bwd returns them
+ * tvae_mmd_tiles(phase): 1 = the part that needs only the prior's image, norms and rec_b (with a gradient: the y-y
+ * sum-only launch), 2 = the rest, 3 = both -- a caller runs phase 1 while the latent images are still on the wire.
+ * tvae_mmd_fwd_bwd is these three stages back to back over all rows.  Inputs are centred on the pooled mean of both
+ * sets in the split modes (the MMD is translation invariant, fp16 pairs are not).  D <= 1024.
+ * layout out[16]: [0] workspace bytes; [1] [2] offsets of the z / y image; [3] bytes per image row; [4] bytes from an
+ * image to its lo image (0: none); [5] [6] offsets of the z / y squared norms (fp32 per row); [7] offset of rec_a
+ * (-1: the mode has no stage A), [8] its doubles (max |value| is the last but one); [9] [10] offsets of rec_b and
+ * rec_b_local, [11] their doubles (the max-norm word is the last but one); [12] offset of gram (-1: none), [13] its
+ * floats; [14] 1: other ranks' lo image rows are read only when 4 max-norm / D^2 >= 1/16 (the caller may skip their
+ * gather otherwise); [15] padded D. */
+int tvae_mmd_shard_layout(int64_t n_total, int64_t n_rows, int64_t D, int want_grad, int dtype, int64_t* out16);
+int tvae_mmd_stats_local(const void* z_loc, const void* y_loc, int64_t n_total, int64_t row_offset, int64_t n_rows,
+                         int64_t D, int dtype, int want_grad, void* workspace, int64_t workspace_bytes, void* stream);
+int tvae_mmd_prep_local(const void* z_loc, const void* y_loc, int64_t n_total, int64_t row_offset, int64_t n_rows,
+                        int64_t D, int dtype, int want_grad, void* workspace, int64_t workspace_bytes, void* stream);
+int tvae_mmd_tiles(const void* z_loc, int64_t n_total, int64_t row_offset, int64_t n_rows, int64_t D, int dtype,
+                   double* sums3, float* loss, double loss_scale, void* d_z, double grad_scale, int phase,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Allocation-free variant of tvae_mmd_fwd_bwd.  NO counterpart in the reference: it exists for callers that
  * cannot allocate device memory around the call (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  Same arguments and results as tvae_mmd_fwd_bwd minus the workspace pair: the scratch

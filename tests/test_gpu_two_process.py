@@ -52,8 +52,10 @@ def _step(vae, h, prior, g0):
     return out.reg_loss.detach().cpu().numpy(), h.grad.cpu().numpy(), out.latent.detach().cpu().numpy(), grads
 
 
-def _worker(rank, world, port, case, out):
+def _worker(rank, world, port, case, out, staged=False):
     import torch.distributed as dist
+    if staged:      # the three-stage form (sharded preparation) at any size; read when transformer_vae_amd.distributed is imported
+        os.environ["TVAE_STAGED_MIN_ELEMENTS"] = "0"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -81,14 +83,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("staged", [False, True], ids=["gathered", "staged"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_two_ranks_on_one_gpu_equal_the_single_process_step(case):
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(case, staged):
+    """``staged``: the preparation is sharded too (distributed._StagedMMD: tvae_mmd_stats_local / _prep_local / _tiles with
+    the collectives between them), which production uses from n_total * D = 2^22 on."""
     import torch.multiprocessing as mp
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q, staged)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])

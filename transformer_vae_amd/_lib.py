@@ -48,6 +48,10 @@ SIGNATURES = {
     "tvae_rbf_kernel_fwd": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "tvae_rbf_kernel_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "tvae_mmd_fwd_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp, _i64, _vp]),
+    "tvae_mmd_shard_layout": (_int, [_i64, _i64, _i64, _int, _int, _vp]),
+    "tvae_mmd_stats_local": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
+    "tvae_mmd_prep_local": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
+    "tvae_mmd_tiles": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _int, _vp, _i64, _vp]),
     "tvae_mmd_fwd_bwd_static": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _f64, _vp, _f64, _vp]),
     "tvae_small_step_supported": (_int, [_i64] * 4),
     "tvae_small_step_fwd_workspace_bytes": (_i64, [_i64] * 4),

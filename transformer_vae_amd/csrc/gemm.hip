@@ -55,6 +55,7 @@ struct GemmArgs {
     // that output column Nb is the column sum of A over k = the bias gradient, written to csum[m] instead of C
     void* csum; int Nb;
     int deep;      // 1: BK_DEEP-deep K tiles (small launches)
+    const float* a_sub; const float* b_sub;      // GemmDesc::a_sub / b_sub (nullable)
 };
 
 // A (64 rows x BKT k) operand tile travels global -> registers -> LDS (as tile[k][row]) in BKT/16 pieces per
@@ -63,7 +64,7 @@ struct GemmArgs {
 // that no load sits behind a bounds check -- was 0-20 % SLOWER at the BASELINE cfg2/cfg3 shapes.)
 template <typename T, bool KMAJOR, int BKT>
 __device__ __forceinline__ void tile_load(float v[BKT / 16][4], const T* __restrict__ P, const RowMap& map, int r0, int R,
-                                          int k0, int kend, bool vec, int tid) {
+                                          int k0, int kend, bool vec, int tid, const float* __restrict__ sub = nullptr) {
 #pragma unroll
     for (int j = 0; j < BKT / 16; ++j) {
         const int q = tid + 256 * j;
@@ -76,6 +77,10 @@ __device__ __forceinline__ void tile_load(float v[BKT / 16][4], const T* __restr
                 const T* p = P + map(r) + k;
                 const int nv = min(4, kend - k);
                 if (vec && nv == 4) load4_vec(p, v[j]); else load4_guard(p, nv, v[j]);
+                if (sub) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nv) v[j][e] -= sub[k + e];
+                }
             }
         } else {
             const int krow = q >> 4, rq = (q & 15) * 4;
@@ -84,6 +89,10 @@ __device__ __forceinline__ void tile_load(float v[BKT / 16][4], const T* __restr
                 const T* p = P + map(k) + r;
                 const int nv = min(4, R - r);
                 if (vec && nv == 4) load4_vec(p, v[j]); else load4_guard(p, nv, v[j]);
+                if (sub) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nv) v[j][e] -= sub[r + e];
+                }
             }
         }
     }
@@ -141,16 +150,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by
     const bool csum = CSUM && a.csum != nullptr;
     const int nb_real = csum ? a.Nb : a.N;                            // columns B really has
     float ra[BKT / 16][4], rb[BKT / 16][4];
-    tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, kbeg, kend, a.vecA, tid);
-    tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, kbeg, kend, a.vecB, tid);
+    tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, kbeg, kend, a.vecA, tid, a.a_sub);
+    tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, kbeg, kend, a.vecB, tid, a.b_sub);
     if (CSUM && csum) tile_ones<BKT>(rb, n0, a.Nb, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BKT) {
         tile_store<A_KMAJOR, BKT>(As, ra, tid);
         tile_store<B_KMAJOR, BKT>(Bs, rb, tid);
         __syncthreads();
         if (k0 + BKT < kend) {      // next tile's loads fly during this tile's MFMAs
-            tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, k0 + BKT, kend, a.vecA, tid);
-            tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, k0 + BKT, kend, a.vecB, tid);
+            tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, k0 + BKT, kend, a.vecA, tid, a.a_sub);
+            tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, k0 + BKT, kend, a.vecB, tid, a.b_sub);
             if (CSUM && csum) tile_ones<BKT>(rb, n0, a.Nb, k0 + BKT, kend, tid);
         }
 #pragma unroll
@@ -532,6 +541,7 @@ int prepare_args(const GemmDesc& g, GemmArgs& a) {
     a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.slab = g.slab;
     a.M = g.M; a.N = g.N + (g.colsum_out ? 1 : 0); a.K = g.K;
     a.csum = g.colsum_out; a.Nb = g.N;
+    a.a_sub = g.a_sub; a.b_sub = g.b_sub;
     a.amap = g.amap; a.bmap = g.bmap; a.cmap = g.cmap;
     choose_split(a.M, a.N, g.K, &a.splits, &a.k_per_split, &a.deep);
     if (a.splits > 1 && (!g.slab || g.slab_floats < (int64_t)a.splits * a.M * a.N)) {

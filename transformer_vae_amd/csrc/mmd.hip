@@ -544,46 +544,123 @@ __device__ __forceinline__ void prep_store(TC* dst, long long idx, long long lo_
     }
 }
 
-// max |value| over both inputs (split kernels' scale), in two plain-store stages: per-block maxima, then one block
-// reduces them -- no atomics and no word that has to start at zero, so nothing depends on a memset node
-constexpr int AMAX_BLOCKS = 1024;
-__global__ __launch_bounds__(256) void mmd_amax_kernel(const float* __restrict__ z, const float* __restrict__ y, long long count,
-                                                       long long n4, float* __restrict__ part) {
-    __shared__ float red[4];
-    float m = 0.f;      // n4: float4 groups read 16 B at a time (0 for unaligned views); the rest element-wise
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 a = reinterpret_cast<const float4*>(z)[i], b = reinterpret_cast<const float4*>(y)[i];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
-    }
-    for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256)
-        m = fmaxf(m, fmaxf(fabsf(z[i]), fabsf(y[i])));
+// ---- The call in three stages (split modes; the other modes have no stage A) --------------------------------------
+//   A  stats : column sums and max |value| of the SOURCE rows of this call                      -> rec_a
+//   B  prep  : images of the source rows CENTRED on the pooled mean mu = (sum z + sum y) / 2N, squared norms,
+//              column sums / third moments / norm sums of the centred rows (-> rec_b), Z'^T Z' and Y'^T Y' of the
+//              source rows (Q-form gradient)
+//   C  tiles : closed-form pieces from the COMPLETE records, tile kernels, finalize
+// One process: the source rows are all rows and the stages run back to back (tvae_mmd_fwd_bwd).  Row-sharded over R
+// ranks (tvae_mmd_stats_local / _prep_local / _tiles): the source rows are the rank's own n / R rows, rec_a is summed
+// over ranks between A and B, and between B and C the image rows and norms are all-gathered (fp16: half the bytes of
+// the fp32 latents) and rec_b and the two D x D matrices summed -- no rank touches another rank's rows before C, so
+// the O(N D) prep and the O(N D^2) closed-form products shrink with R like the tile work does.
+// Centring: MMD and its gradient are invariant under a common translation of both sets, and the split arithmetic is
+// not -- a common offset eats the fp16 pairs' 22 bits (both+5: gradient 1e-4 wrong, tests/test_gpu_r3.py).  The
+// images, norms and every closed-form moment are therefore those of x - mu; only the explicit mean-shift term of the
+// gradient, sum z - sum y, is taken from the uncentred column sums (it is translation invariant and exact there).
+//
+// rec_a (doubles): [0, DPAD) sum z, [DPAD, 2 DPAD) sum y, [2 DPAD] max |value|, [2 DPAD + 1] 0
+// rec_b (doubles): [0, DPAD) sum z', [DPAD ..) sum y', [2 DPAD ..) sum |z'|^2 z', [3 DPAD ..) sum |y'|^2 y',
+//                  [4 DPAD] sum |z'|^2, [+1] sum |y'|^2, [+2] max squared norm, [+3] 0
+__host__ __device__ constexpr int rec_a_doubles(int DPAD) { return 2 * DPAD + 2; }
+__host__ __device__ constexpr int rec_b_doubles(int DPAD) { return 4 * DPAD + 4; }
+
+__device__ __forceinline__ float wave_maxf(float m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-__global__ __launch_bounds__(256) void mmd_amax_final_kernel(const float* __restrict__ part, int nparts, unsigned* __restrict__ out) {
-    __shared__ float red[4];
-    float m = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    return m;
 }
 
+// stage A, first half: per-wave column sums and maxima of rows_per_wave source rows (plain stores, no atomics).
+// fp64 from the first add: the mean-shift term of the gradient, sum z - sum y, comes from these sums, and under a common
+// offset (both+50, tests/test_gpu_r3.py) fp32 partial sums of ~64 rows already cost 1.5e-5 of the gradient
+__global__ __launch_bounds__(256) void mmd_stats_kernel(const float* __restrict__ z, const float* __restrict__ y, int n_src, int D,
+                                                        int DPAD, int rows_per_wave, int nwaves, double* __restrict__ colpart,
+                                                        float* __restrict__ amaxpart) {
+    const int lane = threadIdx.x & 63;
+    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wg >= nwaves) return;
+    const int set = blockIdx.y;
+    const float* __restrict__ src = set ? y : z;
+    const int NJ = (DPAD + 63) / 64;
+    double csum[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) csum[j] = 0.0;
+    float m = 0.f;
+    const int r0 = wg * rows_per_wave, r1 = min(n_src, r0 + rows_per_wave);
+    for (int row = r0; row < r1; ++row) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = lane + 64 * j;
+            if (j < NJ && c < D) {
+                const float v = src[(long long)row * D + c];
+                csum[j] += (double)v;
+                m = fmaxf(m, fabsf(v));
+            }
+        }
+    }
+    double* cp = colpart + ((long long)set * nwaves + wg) * DPAD;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < NJ && lane + 64 * j < DPAD) cp[lane + 64 * j] = csum[j];
+    m = wave_maxf(m);
+    if (lane == 0) amaxpart[set * nwaves + wg] = m;
+}
+
+// stage A, second half: fp64 sums of the partials in a fixed order, one workgroup per 64 columns; workgroup 0 also
+// reduces the maxima
+__global__ __launch_bounds__(1024) void mmd_stats_final_kernel(const double* __restrict__ colpart, const float* __restrict__ amaxpart,
+                                                               int nwaves, int DPAD, double* __restrict__ rec_a) {
+    __shared__ double red[2][16][64];
+    __shared__ float redm[16];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double cz = 0.0, cy = 0.0;
+    if (c < DPAD) {
+#pragma unroll 8
+        for (int w = ry; w < nwaves; w += 16) {
+            cz += colpart[(long long)w * DPAD + c];
+            cy += colpart[((long long)nwaves + w) * DPAD + c];
+        }
+    }
+    red[0][ry][cx] = cz; red[1][ry][cx] = cy;
+    if (blockIdx.x == 0) {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < 2 * nwaves; i += 1024) m = fmaxf(m, amaxpart[i]);
+        m = wave_maxf(m);
+        if (cx == 0) redm[ry] = m;
+    }
+    __syncthreads();
+    if (ry == 0 && c < DPAD) {
+        double tz = 0.0, ty = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { tz += red[0][k][cx]; ty += red[1][k][cx]; }
+        rec_a[c] = tz; rec_a[DPAD + c] = ty;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float m = 0.f;
+        for (int k = 0; k < 16; ++k) m = fmaxf(m, redm[k]);
+        rec_a[2 * DPAD] = (double)m; rec_a[2 * DPAD + 1] = 0.0;
+    }
+}
+
+// stage B: zero-padded images (row stride DPAD; fp32, bf16, or the fp16 pairs of split mode), squared norms, per-wave column
+// sums (and third moments).  The source arrays hold rows [src_row0, ...) of the problem; rows are cut into
+// [0, lo) | [lo, hi) = the rows this call owns | [hi2, n_pad) and each segment into chunks of rows_per_wave, so that
+// waves nw0 .. nw0 + nw1 - 1 hold exactly the owned rows.  One process: src_row0 = 0, hi2 = hi.  A rank of a sharded
+// call: src_row0 = lo, nw0 = 0, hi2 = n_total -- its own rows and the zero rows behind the last point.
+// rec_a non-null (split mode): centre on the pooled mean and take the fp16 scale from max |value| + max |mu|, which
+// bounds every centred magnitude; wave 0 publishes mu and the scale word for the later kernels.
 template <typename T, typename TC, bool SPLIT>
 __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, const T* __restrict__ y, int n_total,
                                                        int n_pad, int D, int DPAD, TC* __restrict__ zp,
                                                        TC* __restrict__ yp, float* __restrict__ zn,
                                                        float* __restrict__ yn, float* __restrict__ colpart,
-                                                       int rows_per_wave, int nwaves, int lo, int hi, int nw0, int nw1,
-                                                       long long lo_off, const unsigned* __restrict__ split_amax,
+                                                       int rows_per_wave, int nwaves, int lo, int hi, int hi2, int nw0, int nw1,
+                                                       int src_row0, long long lo_off, const double* __restrict__ rec_a,
+                                                       double inv_2n, float* __restrict__ mu_out, unsigned* __restrict__ amax_out,
                                                        float* __restrict__ colpart3) {
-    const float scale = SPLIT ? split_scales(*split_amax).s : 1.f;
     const int lane = threadIdx.x & 63;
     const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wg >= nwaves) return;
@@ -592,19 +669,39 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
     TC* __restrict__ dst = set ? yp : zp;
     float* __restrict__ nrm = set ? yn : zn;
     const int NJ = (DPAD + 63) / 64;      // 64-column groups per row (<= 16)
-    float csum[16], csum3[16];      // csum3 (Q-form gradient only): partial sums of |row|^2 row
+    float csum[16], csum3[16], mu[16];      // csum3 (Q-form gradient only): partial sums of |row|^2 row
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { csum[j] = 0.f; csum3[j] = 0.f; }
-    // rows are cut into [0, lo), [lo, hi), [hi, n_pad) -- the local row range of this call is [lo, hi) -- and
-    // each segment into chunks of rows_per_wave: waves nw0 .. nw0 + nw1 - 1 hold exactly the local rows
+    for (int j = 0; j < 16; ++j) { csum[j] = 0.f; csum3[j] = 0.f; mu[j] = 0.f; }
+    float scale = 1.f;
+    if (rec_a) {
+        float mm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = lane + 64 * j;
+            if (j < NJ && c < D) {
+                mu[j] = (float)((rec_a[c] + rec_a[DPAD + c]) * inv_2n);
+                mm = fmaxf(mm, fabsf(mu[j]));
+            }
+        }
+        mm = wave_maxf(mm);
+        const unsigned bits = __float_as_uint((float)rec_a[2 * DPAD] + mm);
+        if (SPLIT) scale = split_scales(bits).s;
+        if (wg == 0 && set == 0) {
+            if (lane == 0) *amax_out = bits;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < NJ && lane + 64 * j < DPAD) mu_out[lane + 64 * j] = mu[j];
+        }
+    }
     int r0, r1;
     if (wg < nw0) { r0 = wg * rows_per_wave; r1 = min(lo, r0 + rows_per_wave); }
     else if (wg < nw0 + nw1) { r0 = lo + (wg - nw0) * rows_per_wave; r1 = min(hi, r0 + rows_per_wave); }
-    else { r0 = hi + (wg - nw0 - nw1) * rows_per_wave; r1 = min(n_pad, r0 + rows_per_wave); }
+    else { r0 = hi2 + (wg - nw0 - nw1) * rows_per_wave; r1 = min(n_pad, r0 + rows_per_wave); }
+    src -= (long long)src_row0 * D;       // indexed by the row of the problem from here on (never dereferenced below src_row0)
     if (NJ <= 4) {
         // narrow rows (DPAD <= 256) carry one to four loads per lane: four rows at a time, every load issued before
-        // the first use (out-of-range elements read src[0] and are zeroed by a select), so a wave pays one memory
-        // latency per four rows instead of one per row (BASELINE cfg3, ten rows per wave: 15 -> 7 us)
+        // the first use (out-of-range elements read the first source element and are zeroed by a select), so a wave pays
+        // one memory latency per four rows instead of one per row (BASELINE cfg3, ten rows per wave: 15 -> 7 us)
         for (int row = r0; row < r1; row += 4) {
             float v[4][4];
 #pragma unroll
@@ -614,8 +711,8 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                 for (int j = 0; j < 4; ++j) {
                     const int c = lane + 64 * j;
                     const bool ok = j < NJ && c < D && rr < r1 && rr < n_total;
-                    const float t = to_f32(src[ok ? (long long)rr * D + c : 0ll]);
-                    v[u][j] = ok ? t : 0.f;
+                    const float t = to_f32(src[ok ? (long long)rr * D + c : (long long)src_row0 * D]);
+                    v[u][j] = ok ? t - mu[j] : 0.f;
                 }
             }
 #pragma unroll
@@ -649,7 +746,7 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
                 const int c = lane + 64 * j;
                 vr[j] = 0.f;
                 if (j < NJ && c < DPAD) {
-                    const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) : 0.f;
+                    const float v = (row < n_total && c < D) ? to_f32(src[(long long)row * D + c]) - mu[j] : 0.f;
                     prep_store<TC, SPLIT>(dst, (long long)row * DPAD + c, lo_off, v, scale);    // TC == bf16 without SPLIT only with T == bf16: exact
                     csum[j] += v;
                     sq = fmaf(v, v, sq);
@@ -676,55 +773,80 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
     }
 }
 
+// stage B, the record: fp64 sums of the per-wave partials in a fixed order -- over every wave (rec_all) and over the
+// waves of the owned rows (rec_loc).  Workgroups 0 .. ncb - 1 take 64 columns each; workgroup ncb sums the squared
+// norms of the source rows [g0, g1) and of the owned rows [lo, hi) and finds the largest.
+__global__ __launch_bounds__(1024) void mmd_recb_kernel(const float* __restrict__ colpart, const float* __restrict__ colpart3,
+                                                        int nwaves, int nw0, int nw1, int DPAD, const float* __restrict__ zn,
+                                                        const float* __restrict__ yn, int g0, int g1, int lo, int hi, int ncb,
+                                                        double* __restrict__ rec_all, double* __restrict__ rec_loc) {
+    __shared__ double red[4][16][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    if ((int)blockIdx.x == ncb) {
+        double az = 0.0, ay = 0.0, azl = 0.0, ayl = 0.0;
+        float mx = 0.f, mxl = 0.f;
+        for (int i = g0 + (int)threadIdx.x; i < g1; i += 1024) {
+            const float a = zn[i], b = yn[i];
+            const bool own = i >= lo && i < hi;
+            az += (double)a; ay += (double)b;
+            mx = fmaxf(mx, fmaxf(a, b));
+            if (own) { azl += (double)a; ayl += (double)b; mxl = fmaxf(mxl, fmaxf(a, b)); }
+        }
+        az = wave_sum(az); ay = wave_sum(ay); azl = wave_sum(azl); ayl = wave_sum(ayl);
+        mx = wave_maxf(mx); mxl = wave_maxf(mxl);
+        if (cx == 0) {
+            red[0][ry][0] = az; red[0][ry][1] = ay; red[0][ry][2] = azl; red[0][ry][3] = ayl;
+            red[0][ry][4] = (double)mx; red[0][ry][5] = (double)mxl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0}, m = 0.0, ml = 0.0;
+            for (int k = 0; k < 16; ++k) {
+                for (int q = 0; q < 4; ++q) t[q] += red[0][k][q];
+                m = fmax(m, red[0][k][4]); ml = fmax(ml, red[0][k][5]);
+            }
+            double* ra = rec_all + 4 * DPAD;
+            double* rl = rec_loc + 4 * DPAD;
+            ra[0] = t[0]; ra[1] = t[1]; ra[2] = m; ra[3] = 0.0;
+            rl[0] = t[2]; rl[1] = t[3]; rl[2] = ml; rl[3] = 0.0;
+        }
+        return;
+    }
+    const int c = blockIdx.x * 64 + cx;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* __restrict__ part = pass ? colpart3 : colpart;
+        double sz = 0.0, sy = 0.0, szl = 0.0, syl = 0.0;
+        if (part && c < DPAD) {
+#pragma unroll 8
+            for (int w = ry; w < nwaves; w += 16) {      // eight independent loads in flight per lane
+                const double vz = (double)part[(long long)w * DPAD + c];
+                const double vy = (double)part[((long long)nwaves + w) * DPAD + c];
+                const bool own = w >= nw0 && w < nw0 + nw1;
+                sz += vz; sy += vy;
+                szl += own ? vz : 0.0; syl += own ? vy : 0.0;
+            }
+        }
+        __syncthreads();
+        red[0][ry][cx] = sz; red[1][ry][cx] = sy; red[2][ry][cx] = szl; red[3][ry][cx] = syl;
+        __syncthreads();
+        if (ry == 0 && c < DPAD) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { t[0] += red[0][k][cx]; t[1] += red[1][k][cx]; t[2] += red[2][k][cx]; t[3] += red[3][k][cx]; }
+            rec_all[(2 * pass) * DPAD + c] = t[0]; rec_all[(2 * pass + 1) * DPAD + c] = t[1];
+            rec_loc[(2 * pass) * DPAD + c] = t[2]; rec_loc[(2 * pass + 1) * DPAD + c] = t[3];
+        }
+    }
+}
+
 // ---- Q-form gradient (split pipelined path): E = -t + Q(t), the part linear in t in closed form ----------------------
 //   sum_p s_p E_kp x_p = -(1/D^2) [ m3 + |z_k|^2 shift - 2 M2 z_k ] + sum_p s_p Q_kp x_p
 //   sum_p s_p E_kp     = -(1/D^2) [ A_z - A_y - 2 shift . z_k ]     + sum_p s_p Q_kp          (sum_p s_p = 0)
 // with m3 = sum_z |z|^2 z - sum_y |y|^2 y, shift = sum z - sum y, M2 = Z^T Z - Y^T Y, A = sums of squared norms.
 // For the shapes that matter t ~ 2 / D, so Q ~ t^2 / 2 is ~1e-3 of E and ONE fp16 product carries the tile kernel's share of
 // the gradient at the accuracy of the fp32 kernel.  Valid while every t of the call is below the
-// polynomial range: the flag kernel bounds t by 4 max |.|^2 / D^2 on the device, and tile kernel and finalize read it.
+// polynomial range: the closed-form kernel bounds t by 4 max |.|^2 / D^2 on the device, and tile kernel and finalize read it.
 struct QFlag { unsigned on; unsigned pad; double az, ay; };      // az, ay: sums of squared norms over all points
-
-__global__ __launch_bounds__(1024) void mmd_qflag_kernel(const float* __restrict__ zn, const float* __restrict__ yn, int n_total,
-                                                          int D, QFlag* __restrict__ out) {
-    __shared__ double rz[16], ry[16];
-    __shared__ float rm[16];
-    double az = 0.0, ay = 0.0;
-    float mx = 0.f;
-    for (int i = threadIdx.x; i < n_total; i += 1024) {
-        const float a = zn[i], b = yn[i];
-        az += (double)a; ay += (double)b;
-        mx = fmaxf(mx, fmaxf(a, b));
-    }
-    az = wave_sum(az); ay = wave_sum(ay);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) { rz[threadIdx.x >> 6] = az; ry[threadIdx.x >> 6] = ay; rm[threadIdx.x >> 6] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double sz = 0.0, sy = 0.0;
-        float m = 0.f;
-        for (int k = 0; k < 16; ++k) { sz += rz[k]; sy += ry[k]; m = fmaxf(m, rm[k]); }
-        // t <= (|x| + |z|)^2 / D^2 <= 4 max|.|^2 / D^2; half the polynomial range leaves room for rounding (NaN: off)
-        const float bound = 4.f * m / ((float)D * (float)D);
-        out->on = (bound < 0.5f * EM1_POLY_MAX) ? 1u : 0u;
-        out->pad = 0u;
-        out->az = sz; out->ay = sy;
-    }
-}
-
-// m3[c] from the per-wave partials (fp64 accumulate, fixed order)
-__global__ __launch_bounds__(256) void mmd_m3_kernel(const float* __restrict__ colpart3, int nwaves, int DPAD, float* __restrict__ m3) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= DPAD) return;
-    double sz = 0.0, sy = 0.0;
-#pragma unroll 8
-    for (int w = 0; w < nwaves; ++w) {
-        sz += (double)colpart3[(long long)w * DPAD + c];
-        sy += (double)colpart3[((long long)nwaves + w) * DPAD + c];
-    }
-    m3[c] = (float)(sz - sy);
-}
 
 // M2 = Z^T Z - Y^T Y (in place over the first) with shift appended as column D: row r of the D x (D + 1) matrix the
 // row product below multiplies by, so that column D of its result is shift . z_k
@@ -738,57 +860,52 @@ __global__ __launch_bounds__(256) void mmd_m2_fix_kernel(float* __restrict__ m2z
     }
 }
 
-// Column moments from the per-wave partials (fp64 accumulate, fixed order):
-//   shift[c] = sum_rows z[.,c] - sum_rows y[.,c]                       (mean-shift term of the gradient)
-//   dots[block][3] = partial dot products over this block's 64 columns of
-//       <c_z^local, c_z>, <c_z^local, c_y>, <c_y^local, c_y>,   c = column sums, local = rows of this call
-// (the closed-form linear part of the three sums, see em1_split in mmd_common.h).
-// One workgroup per 64 columns; 16 row-lanes stride over the partials, then fixed-order LDS reductions.
-__global__ __launch_bounds__(1024) void mmd_moments_kernel(const float* __restrict__ colpart, int nwaves, int nw0, int nw1,
-                                                           int DPAD, float* __restrict__ shift, double* __restrict__ dots) {
-    __shared__ double red[4][16][64];
-    __shared__ double prod[3][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
-    double cz = 0.0, cy = 0.0, czl = 0.0, cyl = 0.0;
+// stage C, first kernel (one workgroup, a thread per column): everything the tile kernels and finalize need from the
+// COMPLETE records --
+//   shift[c] = sum z - sum y      (mean-shift term of the gradient; from rec_a, the uncentred sums, when there is one)
+//   m3[c]                         (Q-form gradient)
+//   dots[3] = <c_z^loc, c_z>, <c_z^loc, c_y>, <c_y^loc, c_y>,   c = column sums of the centred points
+//             (the closed-form linear part of the three sums, see em1_split in mmd_common.h)
+//   the Q-form flag and the norm sums
+__global__ __launch_bounds__(1024) void mmd_closed_kernel(const double* __restrict__ rec_all, const double* __restrict__ rec_loc,
+                                                          const double* __restrict__ rec_a, int D, int DPAD, float* __restrict__ shift,
+                                                          float* __restrict__ m3, double* __restrict__ dots, QFlag* __restrict__ qflag) {
+    __shared__ double red[3][16];
+    const int c = threadIdx.x;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
     if (c < DPAD) {
-#pragma unroll 8
-        for (int w = ry; w < nwaves; w += 16) {      // eight independent loads in flight per lane
-            const double vz = (double)colpart[(long long)w * DPAD + c];
-            const double vy = (double)colpart[((long long)nwaves + w) * DPAD + c];
-            const bool local = w >= nw0 && w < nw0 + nw1;
-            cz += vz; cy += vy;
-            czl += local ? vz : 0.0; cyl += local ? vy : 0.0;
-        }
+        const double cz = rec_all[c], cy = rec_all[DPAD + c], czl = rec_loc[c], cyl = rec_loc[DPAD + c];
+        p0 = czl * cz; p1 = czl * cy; p2 = cyl * cy;
+        shift[c] = rec_a ? (float)(rec_a[c] - rec_a[DPAD + c]) : (float)(cz - cy);
+        if (m3) m3[c] = (float)(rec_all[2 * DPAD + c] - rec_all[3 * DPAD + c]);
     }
-    red[0][ry][cx] = cz; red[1][ry][cx] = cy; red[2][ry][cx] = czl; red[3][ry][cx] = cyl;
-    __syncthreads();
-    if (ry == 0) {
-        double t[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            t[0] += red[0][k][cx]; t[1] += red[1][k][cx]; t[2] += red[2][k][cx]; t[3] += red[3][k][cx];
-        }
-        if (c < DPAD) shift[c] = (float)(t[0] - t[1]);
-        prod[0][cx] = t[2] * t[0]; prod[1][cx] = t[2] * t[1]; prod[2][cx] = t[3] * t[1];
-    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = p0; red[1][threadIdx.x >> 6] = p1; red[2][threadIdx.x >> 6] = p2; }
     __syncthreads();
     if (threadIdx.x < 3) {
         double d = 0.0;
-        for (int k = 0; k < 64; ++k) d += prod[threadIdx.x][k];
-        dots[blockIdx.x * 3 + threadIdx.x] = d;
+        for (int k = 0; k < 16; ++k) d += red[threadIdx.x][k];
+        dots[threadIdx.x] = d;
+    }
+    if (threadIdx.x == 0 && qflag) {
+        // t <= (|x| + |z|)^2 / D^2 <= 4 max|.|^2 / D^2; half the polynomial range leaves room for rounding (NaN: off)
+        const float bound = 4.f * (float)rec_all[4 * DPAD + 2] / ((float)D * (float)D);
+        qflag->on = (bound < 0.5f * EM1_POLY_MAX) ? 1u : 0u;
+        qflag->pad = 0u;
+        qflag->az = rec_all[4 * DPAD]; qflag->ay = rec_all[4 * DPAD + 1];
     }
 }
 
 struct FinalArgs {
     const double* wg_sums; int nwg0, nwg1;   // nwg0 problem-0 workgroups come first, then nwg1 problem-1 ones
-    const double* wg_rowsum; const float* wg_grad; const float* shift; const void* z_src;   // z_src: the caller's z_all (n_total, D)
+    const double* wg_rowsum; const float* wg_grad; const float* shift; const void* z_src;   // z_src: the caller's owned z rows (n_rows, D)
+    const float* mu;                         // pooled mean the images were centred on (null: not centred)
     int col_splits, n_rows, n_rows_pad, row_offset, D, DPAD;
     double* sums3; float* loss; double loss_scale; double grad_scale;
     void* d_z;
     const unsigned* split_amax;   // split kernels: the gradient slabs carry 2^12 s G (split_scales); else null
-    // closed-form linear part: squared norms of all points, the local rows, the column-moment dot products
-    const float* zn; const float* yn; int n_total; const double* dots; int ndots;
+    // closed-form linear part: squared norms of all points, the records, the column-moment dot products
+    const float* zn; int n_total; const double* dots; const double* rec_all; const double* rec_loc;
     // Q-form gradient (null: off): the flag, m3, and P = Z_rows [M2 | shift] (row stride ldP, column D = shift . z_k)
     const QFlag* qflag; const float* m3; const float* P; int ldP;
 };
@@ -816,33 +933,15 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
             }
             __syncthreads();
         }
-        const double qzz = red[0][0], qzy = red[1][0], qyy = red[2][0];     // sums of Q = E + t (second order)
-        __syncthreads();
-        // linear part in closed form:  sum_{i local, j} |a_i - b_j|^2 = N A_loc + n_loc A_all - 2 <c_loc, c_all>
-        double az = 0.0, ay = 0.0, azl = 0.0, ayl = 0.0;
-#pragma unroll 4
-        for (int i = tid; i < f.n_total; i += 256) {
-            const double vz = (double)f.zn[i], vy = (double)f.yn[i];
-            az += vz; ay += vy;
-            if (i >= f.row_offset && i < f.row_offset + f.n_rows) { azl += vz; ayl += vy; }
-        }
-        __shared__ double red4[4][256];
-        red4[0][tid] = az; red4[1][tid] = ay; red4[2][tid] = azl; red4[3][tid] = ayl;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) red4[k][tid] += red4[k][tid + o];
-            }
-            __syncthreads();
-        }
         if (tid == 0) {
-            double dzz = 0.0, dzy = 0.0, dyy = 0.0;
-            for (int k = 0; k < f.ndots; ++k) { dzz += f.dots[3 * k]; dzy += f.dots[3 * k + 1]; dyy += f.dots[3 * k + 2]; }
+            const double qzz = red[0][0], qzy = red[1][0], qyy = red[2][0];     // sums of Q = E + t (second order)
+            // linear part in closed form:  sum_{i owned, j} |a_i - b_j|^2 = N A_loc + n_loc A_all - 2 <c_loc, c_all>
+            const double az = f.rec_all[4 * f.DPAD], ay = f.rec_all[4 * f.DPAD + 1];
+            const double azl = f.rec_loc[4 * f.DPAD], ayl = f.rec_loc[4 * f.DPAD + 1];
             const double N = (double)f.n_total, nl = (double)f.n_rows, inv = 1.0 / ((double)f.D * (double)f.D);
-            const double szz = qzz - (N * red4[2][0] + nl * red4[0][0] - 2.0 * dzz) * inv;
-            const double szy = qzy - (N * red4[2][0] + nl * red4[1][0] - 2.0 * dzy) * inv;
-            const double syy = qyy - (N * red4[3][0] + nl * red4[1][0] - 2.0 * dyy) * inv;
+            const double szz = qzz - (N * azl + nl * az - 2.0 * f.dots[0]) * inv;
+            const double szy = qzy - (N * azl + nl * ay - 2.0 * f.dots[1]) * inv;
+            const double syy = qyy - (N * ayl + nl * ay - 2.0 * f.dots[2]) * inv;
             f.sums3[0] = szz; f.sums3[1] = szy; f.sums3[2] = syy;
             if (f.loss) *f.loss = (float)(f.loss_scale * (syy + szz - 2.0 * szy));
         }
@@ -863,7 +962,9 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
             gsum += f.wg_grad[((long long)s * f.n_rows_pad + row) * f.DPAD + c];
         }
         if (f.split_amax) gsum *= split_scales(*f.split_amax).grad_unscale;       // a power of two: exact
-        const double zv = (double)to_f32(static_cast<const T*>(f.z_src)[((long long)f.row_offset + row) * f.D + c]);
+        float zc = to_f32(static_cast<const T*>(f.z_src)[(long long)row * f.D + c]);
+        if (f.mu) zc -= f.mu[c];      // the same fp32 difference the images were made from
+        const double zv = (double)zc;
         double glin = 0.0;
         if (qf) {
             const float* pr = f.P + (long long)row * f.ldP;
@@ -890,7 +991,7 @@ struct Plan {
     int NB, WAVES, DPAD, n_pad, row_blocks, n_rows_pad, col_splits, tiles_per_set, nwaves, rows_per_wave;
     int sp_major;     // 1: split-major workgroup order (see make_plan)
     int sync_epochs, sync_group, sync_groups;   // soft rendezvous of the gradient launch (sync_epochs == 0: off)
-    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, off_sync, off_amax, off_col3, off_m3, off_m2, off_p, off_gslab, off_qflag, bytes;
+    int64_t off_zp, off_yp, off_zn, off_yn, off_colpart, off_shift, off_dots, off_sums, off_rowsum, off_grad, off_sync, off_amax, off_col3, off_m3, off_m2, off_p, off_gslab, off_qflag, off_reca, off_recb, off_recb_loc, off_mu, bytes;
 };
 
 // (padded dimension, waves per workgroup, 16-column blocks per wave); DPAD = WAVES * 16 * NB
@@ -1048,9 +1149,9 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     p->off_yp = take((int64_t)p->n_pad * p->DPAD * copy_elt);
     p->off_zn = take((int64_t)p->n_pad * 4);
     p->off_yn = take((int64_t)p->n_pad * 4);
-    p->off_colpart = take((int64_t)2 * p->nwaves * p->DPAD * 4);
+    p->off_colpart = take((int64_t)2 * p->nwaves * p->DPAD * (p->split ? 8 : 4));      // split: stage A's fp64 partials first
     p->off_shift = take((int64_t)p->DPAD * 4);
-    p->off_dots = take((int64_t)((p->DPAD + 63) / 64) * 3 * 8);
+    p->off_dots = take(3 * 8);
     p->off_sums = take((int64_t)(2 * p->row_blocks + p->row_blocks_g) * p->col_splits * 2 * 8);
     p->off_rowsum = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * 8 : 0);
     p->off_grad = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * p->DPAD * 4 : 0);
@@ -1063,7 +1164,11 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
         if (epochs >= 1 && slots % 8 == 0 && groups * epochs <= (1 << 17)) { p->sync_epochs = (int)epochs; p->sync_groups = (int)groups; }
     }
     p->off_sync = take((int64_t)p->sync_groups * 8 * p->sync_epochs * 4);
-    p->off_amax = take(p->split ? 256 + AMAX_BLOCKS * 4 : 0);      // the scale word, then the per-block maxima
+    p->off_amax = take(p->split ? 256 + (int64_t)2 * p->nwaves * 4 : 0);      // the scale word, then the per-wave maxima of stage A
+    p->off_reca = take(p->split ? (int64_t)rec_a_doubles(p->DPAD) * 8 : 0);
+    p->off_recb = take((int64_t)rec_b_doubles(p->DPAD) * 8);
+    p->off_recb_loc = take((int64_t)rec_b_doubles(p->DPAD) * 8);
+    p->off_mu = take(p->split ? (int64_t)p->DPAD * 4 : 0);
     p->ldq = (int)align_up(D + 1, 4);
     p->off_col3 = take(p->qform ? (int64_t)2 * p->nwaves * p->DPAD * 4 : 0);
     p->off_m3 = take(p->qform ? (int64_t)p->DPAD * 4 : 0);
@@ -1195,125 +1300,135 @@ extern "C" int64_t tvae_mmd_workspace_bytes_for(int64_t n_total, int64_t n_rows,
 }
 
 namespace {
-int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
-                     int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
-                     double loss_scale, void* d_z, double grad_scale, void* workspace,
-                     int64_t workspace_bytes, void* stream) {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    TVAE_REQUIRE(z_all && y_all && sums3 && workspace, "mmd: null pointer argument");
+// One evaluation, resolved: the plan, the element type of the inputs, and the row ranges.  The SOURCE rows
+// [src_row0, src_row0 + n_src) are the rows whose values this call holds: all of them (one process), or the rows it
+// owns (a rank of a sharded call).
+struct Call {
+    Plan p;
+    int dtype;              // TVAE_F32 / TVAE_BF16: the element type (TVAE_F32_STRICT resolved into the plan)
+    int64_t n_total, row_offset, n_rows, D, src_row0, n_src;
+    char* ws;
+    int rpw, lo, hi, hi2, nw0, nw1, nw2, nwaves;      // row chunks of the prep pass (mmd_prep_kernel)
+    bool centred() const { return p.split != 0; }
+    template <typename U> U* at(int64_t off) const { return reinterpret_cast<U*>(ws + off); }
+};
+
+int resolve_call(Call* c, int64_t n_total, int64_t row_offset, int64_t n_rows, int64_t D, int dtype, bool want_grad, bool sharded,
+                 void* workspace, int64_t workspace_bytes) {
+    TVAE_REQUIRE(workspace, "mmd: null workspace");
     TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16 || dtype == TVAE_F32_STRICT, "mmd: unknown dtype %d", dtype);
-    const int mode = mmd_mode(dtype, D);
-    if (dtype == TVAE_F32_STRICT) dtype = TVAE_F32;          // from here on: the element type of the inputs
     TVAE_REQUIRE(n_total > 0 && n_rows > 0 && D > 0, "mmd: empty problem (n_total=%lld n_rows=%lld D=%lld)",
                  (long long)n_total, (long long)n_rows, (long long)D);
     TVAE_REQUIRE(row_offset >= 0 && row_offset + n_rows <= n_total, "mmd: row block [%lld,%lld) outside [0,%lld)",
                  (long long)row_offset, (long long)(row_offset + n_rows), (long long)n_total);
     TVAE_REQUIRE(n_total < (1ll << 30), "mmd: n_total too large");
-    if (D > 1024) {      // beyond the tile kernels' register budget: strip-wise route through the GEMM kernel
-        const hipEvent_t w0 = g_prof_start, w1 = g_prof_stop;
-        g_prof_start = g_prof_stop = nullptr;
-        if (w0) TVAE_CHECK_HIP(hipEventRecord(w0, s));
-        TVAE_PROPAGATE(mmd_wide_launch(z_all, y_all, n_total, row_offset, n_rows, D, dtype, sums3, loss, loss_scale, d_z,
-                                       grad_scale, workspace, workspace_bytes, s));
-        if (w1) TVAE_CHECK_HIP(hipEventRecord(w1, s));
-        return TVAE_OK;
-    }
-    Plan p;
-    TVAE_REQUIRE(make_plan(n_total, n_rows, D, d_z != nullptr, mode, &p),
-                 "mmd: latent dimension %lld not supported (max 1024)", (long long)D);
-    if (workspace_bytes < p.bytes)
+    TVAE_REQUIRE(make_plan(n_total, n_rows, D, want_grad, mmd_mode(dtype, D), &c->p),
+                 "mmd: latent dimension %lld not supported by the tile kernels (max 1024)", (long long)D);
+    if (workspace_bytes < c->p.bytes)
         return fail(TVAE_ERR_WORKSPACE, "mmd: workspace %lld B < required %lld B", (long long)workspace_bytes,
-                    (long long)p.bytes);
+                    (long long)c->p.bytes);
     TVAE_REQUIRE(aligned16(workspace), "mmd: workspace must be 16-byte aligned");
-    char* ws = static_cast<char*>(workspace);
-    void* zp = ws + p.off_zp;
-    void* yp = ws + p.off_yp;
-    float* zn = reinterpret_cast<float*>(ws + p.off_zn);
-    float* yn = reinterpret_cast<float*>(ws + p.off_yn);
-    float* colpart = reinterpret_cast<float*>(ws + p.off_colpart);
-    float* shift = reinterpret_cast<float*>(ws + p.off_shift);
+    c->dtype = dtype == TVAE_F32_STRICT ? TVAE_F32 : dtype;
+    c->n_total = n_total; c->row_offset = row_offset; c->n_rows = n_rows; c->D = D;
+    c->src_row0 = sharded ? row_offset : 0;
+    c->n_src = sharded ? n_rows : n_total;
+    c->ws = static_cast<char*>(workspace);
+    const int rpw = c->p.rows_per_wave;
+    c->rpw = rpw;
+    c->lo = (int)row_offset; c->hi = (int)(row_offset + n_rows);
+    c->hi2 = sharded ? (int)n_total : c->hi;
+    c->nw0 = sharded ? 0 : (c->lo + rpw - 1) / rpw;
+    c->nw1 = (c->hi - c->lo + rpw - 1) / rpw;
+    c->nw2 = (c->p.n_pad - c->hi2 + rpw - 1) / rpw;
+    c->nwaves = c->nw0 + c->nw1 + c->nw2;          // <= p.nwaves (the plan's bound)
+    return TVAE_OK;
+}
 
-    // row chunks of the prep pass: [0, lo) | [lo, hi) = this call's rows | [hi, n_pad)
-    const int rpw = p.rows_per_wave;
-    const int lo = (int)row_offset, hi = (int)(row_offset + n_rows);
-    const int nw0 = (lo + rpw - 1) / rpw, nw1 = (hi - lo + rpw - 1) / rpw, nw2 = (p.n_pad - hi + rpw - 1) / rpw;
-    const int nwaves = nw0 + nw1 + nw2;          // <= p.nwaves (the plan's bound)
-    dim3 pgrid((nwaves + 3) / 4, 2);
+// stage A (split modes only): rec_a <- column sums and max |value| of the source rows
+int stage_stats(const Call& c, const void* z_src, const void* y_src, hipStream_t s) {
+    if (!c.centred()) return TVAE_OK;
+    const Plan& p = c.p;
+    const int nw = (int)((c.n_src + c.rpw - 1) / c.rpw);
+    double* colpart = c.at<double>(p.off_colpart);
+    float* amaxpart = c.at<float>(p.off_amax + 256);
+    hipLaunchKernelGGL(mmd_stats_kernel, dim3((nw + 3) / 4, 2), dim3(256), 0, s, (const float*)z_src, (const float*)y_src,
+                       (int)c.n_src, (int)c.D, p.DPAD, c.rpw, nw, colpart, amaxpart);
+    TVAE_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mmd_stats_final_kernel, dim3((p.DPAD + 63) / 64), dim3(1024), 0, s, (const double*)colpart,
+                       (const float*)amaxpart, nw, p.DPAD, c.at<double>(p.off_reca));
+    TVAE_CHECK_HIP(hipGetLastError());
+    return TVAE_OK;
+}
+
+// stage B: images, norms and records of the source rows (rec_a complete in the workspace), and for the Q-form gradient
+// Z'^T Z' and Y'^T Y' over the source rows
+int stage_prep(const Call& c, const void* z_src, const void* y_src, hipStream_t s) {
+    const Plan& p = c.p;
+    void* zp = c.ws + p.off_zp;
+    void* yp = c.ws + p.off_yp;
+    float* zn = c.at<float>(p.off_zn);
+    float* yn = c.at<float>(p.off_yn);
+    float* colpart = c.at<float>(p.off_colpart);
+    float* colpart3 = p.qform ? c.at<float>(p.off_col3) : nullptr;
+    const double* rec_a = c.centred() ? c.at<double>(p.off_reca) : nullptr;
+    float* mu = c.centred() ? c.at<float>(p.off_mu) : nullptr;
+    unsigned* amax = c.centred() ? c.at<unsigned>(p.off_amax) : nullptr;
+    const double inv_2n = 0.5 / (double)c.n_total;
     const long long lo_off = (long long)p.n_pad * p.DPAD;      // split: elements from the hi copy to the lo copy
-    unsigned* split_amax = p.split ? reinterpret_cast<unsigned*>(ws + p.off_amax) : nullptr;
-    float* colpart3 = p.qform ? reinterpret_cast<float*>(ws + p.off_col3) : nullptr;
-    if (p.split) {
-        const long long count = (long long)n_total * D;
-        long long ab = (count / 4 + 255) / 256;
-        ab = ab < 1 ? 1 : (ab > AMAX_BLOCKS ? AMAX_BLOCKS : ab);
-        const long long n4 = (aligned16(z_all) && aligned16(y_all)) ? count / 4 : 0;
-        float* amax_part = reinterpret_cast<float*>(ws + p.off_amax + 256);
-        hipLaunchKernelGGL(mmd_amax_kernel, dim3((unsigned)ab), dim3(256), 0, s, (const float*)z_all, (const float*)y_all,
-                           count, n4, amax_part);
-        TVAE_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(mmd_amax_final_kernel, dim3(1), dim3(256), 0, s, (const float*)amax_part, (int)ab, split_amax);
-        TVAE_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL((mmd_prep_kernel<float, _Float16, true>), pgrid, dim3(256), 0, s, (const float*)z_all,
-                           (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (_Float16*)zp, (_Float16*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, lo_off, split_amax, colpart3);
-    }
-    else if (dtype == TVAE_F32)
-        hipLaunchKernelGGL((mmd_prep_kernel<float, float, false>), pgrid, dim3(256), 0, s, (const float*)z_all,
-                           (const float*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr, (float*)nullptr);
-    else if (!p.bf16_tiles)
-        hipLaunchKernelGGL((mmd_prep_kernel<bf16, float, false>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
-                           (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (float*)zp, (float*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr, (float*)nullptr);
-    else
-        hipLaunchKernelGGL((mmd_prep_kernel<bf16, bf16, false>), pgrid, dim3(256), 0, s, (const bf16*)z_all,
-                           (const bf16*)y_all, (int)n_total, p.n_pad, (int)D, p.DPAD, (bf16*)zp, (bf16*)yp, zn, yn,
-                           colpart, rpw, nwaves, lo, hi, nw0, nw1, 0ll, (const unsigned*)nullptr, (float*)nullptr);
+    dim3 pgrid((c.nwaves + 3) / 4, 2);
+#define TVAE_PREP(T, TC, SPLIT)                                                                                          \
+    hipLaunchKernelGGL((mmd_prep_kernel<T, TC, SPLIT>), pgrid, dim3(256), 0, s, (const T*)z_src, (const T*)y_src,       \
+                       (int)c.n_total, p.n_pad, (int)c.D, p.DPAD, (TC*)zp, (TC*)yp, zn, yn, colpart, c.rpw, c.nwaves,  \
+                       c.lo, c.hi, c.hi2, c.nw0, c.nw1, (int)c.src_row0, (SPLIT) ? lo_off : 0ll, rec_a, inv_2n, mu,    \
+                       amax, colpart3)
+    if (p.split) TVAE_PREP(float, _Float16, true);
+    else if (c.dtype == TVAE_F32) TVAE_PREP(float, float, false);
+    else if (!p.bf16_tiles) TVAE_PREP(bf16, float, false);
+    else TVAE_PREP(bf16, bf16, false);
+#undef TVAE_PREP
     TVAE_CHECK_HIP(hipGetLastError());
-    double* dots = reinterpret_cast<double*>(ws + p.off_dots);
-    const int ndots = (p.DPAD + 63) / 64;
-    hipLaunchKernelGGL(mmd_moments_kernel, dim3(ndots), dim3(1024), 0, s, colpart, nwaves, nw0, nw1, p.DPAD, shift, dots);
+    const int ncb = (p.DPAD + 63) / 64;
+    hipLaunchKernelGGL(mmd_recb_kernel, dim3(ncb + 1), dim3(1024), 0, s, (const float*)colpart, (const float*)colpart3, c.nwaves,
+                       c.nw0, c.nw1, p.DPAD, (const float*)zn, (const float*)yn, (int)c.src_row0, (int)(c.src_row0 + c.n_src),
+                       c.lo, c.hi, ncb, c.at<double>(p.off_recb), c.at<double>(p.off_recb_loc));
     TVAE_CHECK_HIP(hipGetLastError());
-
-    // Q-form gradient: the closed-form linear part (see QFlag) -- flag and norm sums, m3, M2 = Z^T Z - Y^T Y with shift as
-    // an extra column, P = Z_rows [M2 | shift]; all on this stream, behind prep and moments
-    QFlag* qflag = nullptr;
-    float* m3 = nullptr;
-    float* pmat = nullptr;
-    if (p.qform || p.qsum) {
-        qflag = reinterpret_cast<QFlag*>(ws + p.off_qflag);
-        hipLaunchKernelGGL(mmd_qflag_kernel, dim3(1), dim3(1024), 0, s, (const float*)zn, (const float*)yn, (int)n_total, (int)D, qflag);
-        TVAE_CHECK_HIP(hipGetLastError());
-    }
     if (p.qform) {
-        m3 = reinterpret_cast<float*>(ws + p.off_m3);
-        pmat = reinterpret_cast<float*>(ws + p.off_p);
-        float* m2z = reinterpret_cast<float*>(ws + p.off_m2);
-        float* m2y = m2z + (long long)D * p.ldq;
-        float* gslab = reinterpret_cast<float*>(ws + p.off_gslab);
-        hipLaunchKernelGGL(mmd_m3_kernel, dim3((p.DPAD + 255) / 256), dim3(256), 0, s, (const float*)colpart3, nwaves, p.DPAD, m3);
-        TVAE_CHECK_HIP(hipGetLastError());
+        float* m2z = c.at<float>(p.off_m2);
+        float* m2y = m2z + (long long)c.D * p.ldq;
         GemmDesc g{};
         g.bias = nullptr; g.epilogue = EPI_NONE; g.dtype = TVAE_F32; g.colsum_out = nullptr;
-        g.M = (int)D; g.N = (int)D; g.K = (int)n_total;
+        g.M = (int)c.D; g.N = (int)c.D; g.K = (int)c.n_src;
         g.a_kmajor = true; g.b_kmajor = true;
-        g.amap = dense_rows(D); g.bmap = dense_rows(D); g.cmap = dense_rows(p.ldq);
-        g.slab = gslab; g.slab_floats = gemm_slab_floats((int)D, (int)D, (int)n_total);
-        g.A = z_all; g.B = z_all; g.C = m2z;
+        g.amap = dense_rows(c.D); g.bmap = dense_rows(c.D); g.cmap = dense_rows(p.ldq);
+        g.slab = c.at<float>(p.off_gslab); g.slab_floats = gemm_slab_floats((int)c.D, (int)c.D, (int)c.n_src);
+        g.a_sub = mu; g.b_sub = mu;
+        g.A = z_src; g.B = z_src; g.C = m2z;
         TVAE_PROPAGATE(gemm_launch(g, s));
-        g.A = y_all; g.B = y_all; g.C = m2y;
+        g.A = y_src; g.B = y_src; g.C = m2y;
         TVAE_PROPAGATE(gemm_launch(g, s));
-        hipLaunchKernelGGL(mmd_m2_fix_kernel, dim3(256), dim3(256), 0, s, m2z, (const float*)m2y, (const float*)shift, (int)D, p.ldq);
-        TVAE_CHECK_HIP(hipGetLastError());
-        GemmDesc h{};
-        h.bias = nullptr; h.epilogue = EPI_NONE; h.dtype = TVAE_F32; h.colsum_out = nullptr;
-        h.M = (int)n_rows; h.N = (int)D + 1; h.K = (int)D;
-        h.a_kmajor = false; h.b_kmajor = true;
-        h.amap = dense_rows(D); h.bmap = dense_rows(p.ldq); h.cmap = dense_rows(p.ldq);
-        h.slab = gslab; h.slab_floats = gemm_slab_floats((int)n_rows, (int)D + 1, (int)D);
-        h.A = static_cast<const float*>(z_all) + row_offset * D; h.B = m2z; h.C = pmat;
-        TVAE_PROPAGATE(gemm_launch(h, s));
     }
+    return TVAE_OK;
+}
+
+// stage C: the closed-form pieces from the complete records, the tile kernels, finalize.
+// z_rows: the owned rows' values.  phase bit 0: everything that needs only the prior's image (the closed-form
+// kernel and, with a gradient, the y-y sum-only launch); bit 1: the rest.  A sharded caller runs phase 1 while the
+// latent images are still on the wire.
+int stage_tiles(const Call& c, const void* z_rows, double* sums3, float* loss, double loss_scale, void* d_z, double grad_scale,
+                int phase, hipStream_t s) {
+    const Plan& p = c.p;
+    const int64_t D = c.D, n_rows = c.n_rows, n_total = c.n_total, row_offset = c.row_offset;
+    void* zp = c.ws + p.off_zp;
+    void* yp = c.ws + p.off_yp;
+    float* zn = c.at<float>(p.off_zn);
+    float* yn = c.at<float>(p.off_yn);
+    float* shift = c.at<float>(p.off_shift);
+    double* dots = c.at<double>(p.off_dots);
+    unsigned* split_amax = p.split ? c.at<unsigned>(p.off_amax) : nullptr;
+    QFlag* qflag = (p.qform || p.qsum) ? c.at<QFlag>(p.off_qflag) : nullptr;
+    float* m3 = p.qform ? c.at<float>(p.off_m3) : nullptr;
+    float* pmat = p.qform ? c.at<float>(p.off_p) : nullptr;
+    const long long lo_off = (long long)p.n_pad * p.DPAD;
 
     MmdArgs a;
     a.cols[0] = (const float*)zp; a.cols[1] = (const float*)yp; a.cnorm[0] = zn; a.cnorm[1] = yn;
@@ -1332,14 +1447,45 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     a.sync_ctr = nullptr; a.sync_epochs = p.sync_epochs; a.sync_group = p.sync_group; a.launch_blocks = 0;
     const int sym_rows = p.n16 ? 16 * p.RT : ((p.narrow64 || p.pipe_sum) ? 64 : ROWS_PER_WG);      // row block of the symmetric y-y enumeration
     a.sym = (row_offset % sym_rows == 0 && (n_rows % sym_rows == 0 || row_offset + n_rows == n_total)) ? 1 : 0;
-    a.wg_sums = reinterpret_cast<double*>(ws + p.off_sums);
-    a.wg_rowsum = reinterpret_cast<double*>(ws + p.off_rowsum);
-    a.wg_grad = reinterpret_cast<float*>(ws + p.off_grad);
+    a.wg_sums = c.at<double>(p.off_sums);
+    a.wg_rowsum = c.at<double>(p.off_rowsum);
+    a.wg_grad = c.at<float>(p.off_grad);
     // workgroups of the two problems (the bf16 gradient launch has its own, larger, row blocks)
     const int nwg_sum = p.row_blocks * p.col_splits;
     const int nwg0 = d_z ? p.row_blocks_g * p.col_splits : nwg_sum, nwg1 = nwg_sum;
+    // the y-y problem as a launch of its own (the others put both problems into one launch)
+    const bool yy_alone = d_z && !p.n16 && !(!p.bf16_tiles && !p.narrow64 && p.WAVES == 1);
+
+    if (phase & 1) {
+        hipLaunchKernelGGL(mmd_closed_kernel, dim3(1), dim3(1024), 0, s, (const double*)c.at<double>(p.off_recb),
+                           (const double*)c.at<double>(p.off_recb_loc), (const double*)(c.centred() ? c.at<double>(p.off_reca) : nullptr),
+                           (int)D, p.DPAD, shift, m3, dots, qflag);
+        TVAE_CHECK_HIP(hipGetLastError());
+        if (yy_alone && phase == 1) {      // (phase 3: behind the gradient launch, inside the profiling bracket)
+            a.problem_base = 1; a.sums_base = nwg0; a.row_blocks = p.row_blocks;
+            TVAE_PROPAGATE(launch_tiles<false>(p, a, nwg1, s));    // y rows: sum only
+        }
+    }
+    if (!(phase & 2)) return TVAE_OK;
+
+    // Q-form gradient: M2 = Z^T Z - Y^T Y with shift as an extra column, P = Z_rows [M2 | shift]
+    if (p.qform) {
+        float* m2z = c.at<float>(p.off_m2);
+        float* m2y = m2z + (long long)D * p.ldq;
+        hipLaunchKernelGGL(mmd_m2_fix_kernel, dim3(256), dim3(256), 0, s, m2z, (const float*)m2y, (const float*)shift, (int)D, p.ldq);
+        TVAE_CHECK_HIP(hipGetLastError());
+        GemmDesc h{};
+        h.bias = nullptr; h.epilogue = EPI_NONE; h.dtype = TVAE_F32; h.colsum_out = nullptr;
+        h.M = (int)n_rows; h.N = (int)D + 1; h.K = (int)D;
+        h.a_kmajor = false; h.b_kmajor = true;
+        h.amap = dense_rows(D); h.bmap = dense_rows(p.ldq); h.cmap = dense_rows(p.ldq);
+        h.slab = c.at<float>(p.off_gslab); h.slab_floats = gemm_slab_floats((int)n_rows, (int)D + 1, (int)D);
+        h.a_sub = c.at<float>(p.off_mu);
+        h.A = z_rows; h.B = m2z; h.C = pmat;
+        TVAE_PROPAGATE(gemm_launch(h, s));
+    }
     if (d_z && p.sync_epochs > 0)        // arrival counters of the soft rendezvous (a memset node under graph capture)
-        TVAE_CHECK_HIP(hipMemsetAsync(ws + p.off_sync, 0, (size_t)p.sync_groups * 8 * p.sync_epochs * 4, s));
+        TVAE_CHECK_HIP(hipMemsetAsync(c.ws + p.off_sync, 0, (size_t)p.sync_groups * 8 * p.sync_epochs * 4, s));
     const hipEvent_t ev0 = g_prof_start, ev1 = g_prof_stop;
     g_prof_start = g_prof_stop = nullptr;
     if (ev0) TVAE_CHECK_HIP(hipEventRecord(ev0, s));
@@ -1347,20 +1493,22 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
         // narrow split mode: both problems in one launch, with or without the gradient
         a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks;
         TVAE_PROPAGATE(launch_mmd_n16(d_z != nullptr, p.NB, a, nwg0, nwg1, s));
-    } else if (d_z && !p.bf16_tiles && !p.narrow64 && p.WAVES == 1) {
+    } else if (d_z && !yy_alone) {
         // single-wave shapes: both problems in one launch (row blocks are the same 32 rows in both)
         a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks;
         TVAE_PROPAGATE(launch_tile_both_shape(p.DPAD, a, nwg0, nwg1, s));
     } else if (d_z) {
         a.problem_base = 0; a.sums_base = 0; a.row_blocks = p.row_blocks_g;
         if (p.sync_epochs > 0) {
-            a.sync_ctr = reinterpret_cast<unsigned*>(ws + p.off_sync);
+            a.sync_ctr = c.at<unsigned>(p.off_sync);
             a.launch_blocks = nwg0;
         }
         TVAE_PROPAGATE(launch_tiles<true>(p, a, nwg0, s));              // z rows: sums + gradient
-        a.sync_ctr = nullptr;
-        a.problem_base = 1; a.sums_base = nwg0; a.row_blocks = p.row_blocks;
-        TVAE_PROPAGATE(launch_tiles<false>(p, a, nwg1, s));    // y rows: sum only
+        if (phase == 3) {
+            a.sync_ctr = nullptr;
+            a.problem_base = 1; a.sums_base = nwg0; a.row_blocks = p.row_blocks;
+            TVAE_PROPAGATE(launch_tiles<false>(p, a, nwg1, s));    // y rows: sum only
+        }
     } else {
         a.problem_base = 0; a.sums_base = 0;
         TVAE_PROPAGATE(launch_tiles<false>(p, a, 2 * nwg_sum, s));
@@ -1368,20 +1516,51 @@ int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int6
     if (ev1) TVAE_CHECK_HIP(hipEventRecord(ev1, s));
 
     FinalArgs f;
-    f.wg_sums = a.wg_sums; f.nwg0 = nwg0; f.nwg1 = nwg1; f.wg_rowsum = a.wg_rowsum; f.wg_grad = a.wg_grad; f.shift = shift; f.z_src = z_all;
+    f.wg_sums = a.wg_sums; f.nwg0 = nwg0; f.nwg1 = nwg1; f.wg_rowsum = a.wg_rowsum; f.wg_grad = a.wg_grad; f.shift = shift; f.z_src = z_rows;
+    f.mu = c.centred() ? c.at<float>(p.off_mu) : nullptr;
     f.col_splits = p.col_splits; f.n_rows = (int)n_rows; f.n_rows_pad = p.n_rows_pad; f.row_offset = (int)row_offset;
     f.D = (int)D; f.DPAD = p.DPAD; f.sums3 = sums3; f.loss = loss; f.loss_scale = loss_scale; f.grad_scale = grad_scale;
     f.d_z = d_z;
     f.split_amax = split_amax;
-    f.zn = zn; f.yn = yn; f.n_total = (int)n_total; f.dots = dots; f.ndots = ndots;
+    f.zn = zn; f.n_total = (int)n_total; f.dots = dots;
+    f.rec_all = c.at<double>(p.off_recb); f.rec_loc = c.at<double>(p.off_recb_loc);
     f.qflag = p.qform ? qflag : nullptr; f.m3 = m3; f.P = pmat; f.ldP = p.ldq;
     long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
     if (fb > 4096) fb = 4096;
     if (fb < 1) fb = 1;
-    if (dtype == TVAE_F32) hipLaunchKernelGGL((mmd_finalize_kernel<float>), dim3((unsigned)fb), dim3(256), 0, s, f);
+    if (c.dtype == TVAE_F32) hipLaunchKernelGGL((mmd_finalize_kernel<float>), dim3((unsigned)fb), dim3(256), 0, s, f);
     else hipLaunchKernelGGL((mmd_finalize_kernel<bf16>), dim3((unsigned)fb), dim3(256), 0, s, f);
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
+}
+
+int mmd_fwd_bwd_impl(const void* z_all, const void* y_all, int64_t n_total, int64_t row_offset,
+                     int64_t n_rows, int64_t D, int dtype, double* sums3, float* loss,
+                     double loss_scale, void* d_z, double grad_scale, void* workspace,
+                     int64_t workspace_bytes, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TVAE_REQUIRE(z_all && y_all && sums3 && workspace, "mmd: null pointer argument");
+    TVAE_REQUIRE(dtype == TVAE_F32 || dtype == TVAE_BF16 || dtype == TVAE_F32_STRICT, "mmd: unknown dtype %d", dtype);
+    if (D > 1024) {      // beyond the tile kernels' register budget: strip-wise route through the GEMM kernel
+        TVAE_REQUIRE(n_total > 0 && n_rows > 0, "mmd: empty problem (n_total=%lld n_rows=%lld D=%lld)",
+                     (long long)n_total, (long long)n_rows, (long long)D);
+        TVAE_REQUIRE(row_offset >= 0 && row_offset + n_rows <= n_total, "mmd: row block [%lld,%lld) outside [0,%lld)",
+                     (long long)row_offset, (long long)(row_offset + n_rows), (long long)n_total);
+        TVAE_REQUIRE(n_total < (1ll << 30), "mmd: n_total too large");
+        const hipEvent_t w0 = g_prof_start, w1 = g_prof_stop;
+        g_prof_start = g_prof_stop = nullptr;
+        if (w0) TVAE_CHECK_HIP(hipEventRecord(w0, s));
+        TVAE_PROPAGATE(mmd_wide_launch(z_all, y_all, n_total, row_offset, n_rows, D, dtype == TVAE_F32_STRICT ? TVAE_F32 : dtype, sums3,
+                                       loss, loss_scale, d_z, grad_scale, workspace, workspace_bytes, s));
+        if (w1) TVAE_CHECK_HIP(hipEventRecord(w1, s));
+        return TVAE_OK;
+    }
+    Call c;
+    TVAE_PROPAGATE(resolve_call(&c, n_total, row_offset, n_rows, D, dtype, d_z != nullptr, false, workspace, workspace_bytes));
+    TVAE_PROPAGATE(stage_stats(c, z_all, y_all, s));
+    TVAE_PROPAGATE(stage_prep(c, z_all, y_all, s));
+    const size_t elt = c.dtype == TVAE_F32 ? 4 : 2;
+    return stage_tiles(c, static_cast<const char*>(z_all) + (size_t)row_offset * D * elt, sums3, loss, loss_scale, d_z, grad_scale, 3, s);
 }
 }  // namespace
 
@@ -1391,6 +1570,63 @@ extern "C" int tvae_mmd_fwd_bwd(const void* z_all, const void* y_all, int64_t n_
                                 int64_t workspace_bytes, void* stream) {
     return mmd_fwd_bwd_impl(z_all, y_all, n_total, row_offset, n_rows, D, dtype, sums3, loss, loss_scale, d_z, grad_scale,
                             workspace, workspace_bytes, stream);
+}
+
+// ---- row-sharded evaluation: the three stages as entry points (see "The call in three stages" above) ---------------
+// Every rank passes the SAME (n_total, n_rows, D, want_grad, dtype) plan arguments and its own row_offset; equal row
+// counts per rank, row_offset = rank * n_rows.
+extern "C" int tvae_mmd_shard_layout(int64_t n_total, int64_t n_rows, int64_t D, int want_grad, int dtype, int64_t* out) {
+    TVAE_REQUIRE(out, "mmd_shard_layout: null output");
+    if (dtype != TVAE_F32 && dtype != TVAE_BF16 && dtype != TVAE_F32_STRICT) return fail(TVAE_ERR_ARG, "mmd_shard_layout: unknown dtype %d", dtype);
+    Plan p;
+    if (n_total <= 0 || n_rows <= 0 || D <= 0 || D > 1024 || n_total >= (1ll << 30) ||
+        !make_plan(n_total, n_rows, D, want_grad != 0, mmd_mode(dtype, D), &p))
+        return fail(TVAE_ERR_ARG, "mmd_shard_layout: no sharded form for n_total=%lld n_rows=%lld D=%lld (tile kernels: D <= 1024)",
+                    (long long)n_total, (long long)n_rows, (long long)D);
+    const int64_t elt = p.split ? 2 : ((p.bf16_tiles) ? 2 : 4);
+    const int64_t img = (int64_t)p.n_pad * p.DPAD * elt;          // one image (split: hi; the lo image follows it)
+    out[0] = p.bytes;
+    out[1] = p.off_zp; out[2] = p.off_yp;
+    out[3] = (int64_t)p.DPAD * elt;                               // bytes per image row
+    out[4] = p.split ? img : 0;                                   // bytes from an image to its lo image (0: there is none)
+    out[5] = p.off_zn; out[6] = p.off_yn;                         // squared norms, fp32 per row
+    out[7] = p.split ? p.off_reca : -1;                           // stage-A record (fp64), -1: the mode has no stage A
+    out[8] = p.split ? rec_a_doubles(p.DPAD) : 0;
+    out[9] = p.off_recb; out[10] = p.off_recb_loc; out[11] = rec_b_doubles(p.DPAD);
+    out[12] = p.qform ? p.off_m2 : -1;                            // Z'^T Z' then Y'^T Y' (fp32), summed over ranks; -1: none
+    out[13] = p.qform ? (int64_t)2 * D * p.ldq : 0;               // ... floats
+    out[14] = (p.split && p.qsum && (!want_grad || (p.qform && p.pipe))) ? 1 : 0;   // 1: the lo images of OTHER ranks' rows are read only when the Q-form flag is off
+    out[15] = p.DPAD;
+    return TVAE_OK;
+}
+
+extern "C" int tvae_mmd_stats_local(const void* z_loc, const void* y_loc, int64_t n_total, int64_t row_offset, int64_t n_rows,
+                                    int64_t D, int dtype, int want_grad, void* workspace, int64_t workspace_bytes, void* stream) {
+    TVAE_REQUIRE(z_loc && y_loc, "mmd_stats_local: null pointer argument");
+    TVAE_REQUIRE(D <= 1024, "mmd_stats_local: D = %lld has no sharded form (tile kernels: D <= 1024)", (long long)D);
+    Call c;
+    TVAE_PROPAGATE(resolve_call(&c, n_total, row_offset, n_rows, D, dtype, want_grad != 0, true, workspace, workspace_bytes));
+    return stage_stats(c, z_loc, y_loc, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tvae_mmd_prep_local(const void* z_loc, const void* y_loc, int64_t n_total, int64_t row_offset, int64_t n_rows,
+                                   int64_t D, int dtype, int want_grad, void* workspace, int64_t workspace_bytes, void* stream) {
+    TVAE_REQUIRE(z_loc && y_loc, "mmd_prep_local: null pointer argument");
+    TVAE_REQUIRE(D <= 1024, "mmd_prep_local: D = %lld has no sharded form (tile kernels: D <= 1024)", (long long)D);
+    Call c;
+    TVAE_PROPAGATE(resolve_call(&c, n_total, row_offset, n_rows, D, dtype, want_grad != 0, true, workspace, workspace_bytes));
+    return stage_prep(c, z_loc, y_loc, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int tvae_mmd_tiles(const void* z_loc, int64_t n_total, int64_t row_offset, int64_t n_rows, int64_t D, int dtype,
+                              double* sums3, float* loss, double loss_scale, void* d_z, double grad_scale, int phase,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    TVAE_REQUIRE(z_loc && sums3, "mmd_tiles: null pointer argument");
+    TVAE_REQUIRE(phase >= 1 && phase <= 3, "mmd_tiles: phase %d (1: prior-only part, 2: the rest, 3: both)", phase);
+    TVAE_REQUIRE(D <= 1024, "mmd_tiles: D = %lld has no sharded form (tile kernels: D <= 1024)", (long long)D);
+    Call c;
+    TVAE_PROPAGATE(resolve_call(&c, n_total, row_offset, n_rows, D, dtype, d_z != nullptr, true, workspace, workspace_bytes));
+    return stage_tiles(c, z_loc, sums3, loss, loss_scale, d_z, grad_scale, phase, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------

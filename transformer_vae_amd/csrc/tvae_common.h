@@ -166,6 +166,10 @@ struct GemmDesc {
     // bias gradient, computed by the same launch through a virtual column of ones appended to B (size the slabs
     // with N + 1 columns)
     void* colsum_out;
+    // nullable fp32 vectors subtracted from the operands as they are loaded, indexed by the operand's CONTIGUOUS index
+    // (k for a row-major operand, m / n for a k-major one): products of centred data without a centred copy (mmd.hip).
+    // Honoured by gemm_launch only (not by the pair / LayerNorm forms).
+    const float* a_sub = nullptr; const float* b_sub = nullptr;
 };
 int64_t gemm_slab_floats(int M, int N, int K);
 int gemm_launch(const GemmDesc& g, hipStream_t stream);

@@ -532,6 +532,54 @@ def mmd_row_block(z_rows, z_all, y_all, row_offset: int, loss_scale: float, grad
                                  bool(strict_fp32), torch.is_grad_enabled())
 
 
+class HipShardStages:
+    """The three stages of a row-sharded MMD evaluation over the C ABI (include/tvae_hip.h: tvae_mmd_shard_layout,
+    tvae_mmd_stats_local, tvae_mmd_prep_local, tvae_mmd_tiles).  ``distributed.sharded_mmd_reg_loss`` owns the collectives
+    between them; a test may hand it another object with these four methods to rehearse them without a GPU."""
+
+    @staticmethod
+    def layout(n_total: int, n_rows: int, dim: int, want_grad: bool, code: int):
+        """The 16 layout words, or None when the shape has no sharded form (latent_size > 1024)."""
+        import ctypes
+        if dim > 1024:
+            return None
+        out = (ctypes.c_int64 * 16)()
+        _lib.check(_lib.lib().tvae_mmd_shard_layout(n_total, n_rows, dim, int(want_grad), code, ctypes.addressof(out)),
+                   "tvae_mmd_shard_layout")
+        return [int(v) for v in out]
+
+    @staticmethod
+    def workspace(nbytes: int, device):
+        return _workspace(nbytes, device)
+
+    @staticmethod
+    @_on_tensor_device
+    def stats(z, y, n_total, row_offset, code, want_grad, ws):
+        n_rows, dim = z.shape
+        _lib.check(_lib.lib().tvae_mmd_stats_local(_ptr(z), _ptr(y), n_total, row_offset, n_rows, dim, code, int(want_grad),
+                                                   _ptr(ws), ws.numel(), _stream(z)), "tvae_mmd_stats_local")
+
+    @staticmethod
+    @_on_tensor_device
+    def prep(z, y, n_total, row_offset, code, want_grad, ws):
+        n_rows, dim = z.shape
+        _lib.check(_lib.lib().tvae_mmd_prep_local(_ptr(z), _ptr(y), n_total, row_offset, n_rows, dim, code, int(want_grad),
+                                                  _ptr(ws), ws.numel(), _stream(z)), "tvae_mmd_prep_local")
+
+    @staticmethod
+    @_on_tensor_device
+    def tiles(z, n_total, row_offset, code, sums, loss, loss_scale, dz, grad_scale, phase, ws):
+        n_rows, dim = z.shape
+        _lib.check(_lib.lib().tvae_mmd_tiles(_ptr(z), n_total, row_offset, n_rows, dim, code, _ptr(sums), _ptr(loss),
+                                             float(loss_scale), _ptr(dz), float(grad_scale), int(phase), _ptr(ws), ws.numel(),
+                                             _stream(z)), "tvae_mmd_tiles")
+
+
+def mmd_code(dtype: torch.dtype, strict_fp32: bool) -> int:
+    """The C ABI's dtype word of an MMD call."""
+    return _mmd_code(dtype, strict_fp32)
+
+
 def bottleneck_step(h, We, be, Wd, bd, gamma, beta, prior, n_tokens: int, eps: float, strict_fp32: bool = False):
     """(latent, reconstructed_encoding, reg_loss) of the stock bottleneck as one autograd node."""
     return _BottleneckStep.apply(h, We, be, Wd, bd, gamma, beta, prior, int(n_tokens), float(eps), bool(strict_fp32),
