@@ -82,28 +82,33 @@ def mmd_roofline(mode, L, achieved, kern_ms, launches, traffic=None):
     HIP events of tvae_profile_next_mmd).  `achieved` counts ALGORITHMIC flops, 10 N_rows N D."""
     pipe = 192 < L <= 768
     if mode == "split":
-        # fp16 products per fp32 product: Gram two (three up to 64 features); gradient three, or ONE beyond 192 features,
-        # where the gradient sums carry Q = E + t with the linear part in closed form (DESIGN 4.1g).  6 of the 10
-        # algorithmic flops are Gram, 4 gradient
-        gram_p, grad_p = (2 if L > 64 else 3), (1 if L > 192 else 3)
+        # fp16 products per fp32 product.  192 < L <= 768 (mmd_q32.hip): ONE for the Gram and ONE for the gradient -- both sums
+        # carry Q = E + t, the part linear in t is closed form (DESIGN 4.1g/4.1h), so executed = algorithmic.  768 < L <= 1024:
+        # Gram two, gradient one.  Narrow latents (mmd_n16.hip): three and three.  6 of the 10 algorithmic flops are Gram, 4 gradient
+        if pipe:
+            gram_p, grad_p = 1, 1
+        elif L > 192:
+            gram_p, grad_p = 2, 1
+        else:
+            gram_p, grad_p = 3, 3
         split_exec = (6 * gram_p + 4 * grad_p) / 10.0
         return {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None, "traffic": traffic,
                 "kernel": ("mmd_n16_kernel<KBN,RT,*>" if L <= 192 else
-                           "mmd_pipe_kernel<KB,true,true> (Q-form) + mmd_pipe_sum_kernel<KB,true>" if pipe else "mmd_bf16_kernel<KB,2,*,true,*> (Q-form gradient launch)"),
+                           "mmd_q32_kernel<KB> (gradient launch) + mmd_q32_sum_kernel<KB> (y-y sums)" if pipe else "mmd_bf16_kernel<KB,2,*,true,*> (Q-form gradient launch)"),
                 "kernel_ms": kern_ms, "launches_timed": launches,
                 "products_per_fp32_product": {"gram": gram_p, "gradient": grad_p},
                 "executed_per_algorithmic": split_exec,
                 "executed_tflops": split_exec * achieved if achieved else None,
                 "frac_executed": split_exec * achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None,
-                "peak_note": "fp16 MFMA dense peak (v_mfma_f32_16x16x32_f16 / 32x32x16_f16).  fp32 operands are scaled fp16 pairs hi + lo; "
-                             "a Gram entry is TWO fp16 matrix products (X_hi Z_hi + X_hi Z_lo: row side exact, column side hi only -- "
-                             "DESIGN 4.1d; three up to 64 features), a gradient entry THREE (hi*hi + lo*hi + hi*lo) or, for "
-                             "192 < D <= 1024, ONE: there the gradient sums carry Q = E + t and the linear part is closed form "
-                             "(third moments, Z^T Z - Y^T Y; DESIGN 4.1g).  Of the 10 N^2 D algorithmic flops 6 are Gram and 4 gradient, "
-                             "so the kernels execute `executed_per_algorithmic` x the algorithmic count: `frac` is algorithmic / peak, "
-                             "`frac_executed` counts the executed products (upper bound: the symmetric y-y launch executes half of "
-                             "its share; the small fp32 GEMMs of the closed form, ~1.5 % of the call, are outside the timed kernels)"}
+                "peak_note": "fp16 MFMA dense peak (v_mfma_f32_32x32x16_f16 / 16x16x32_f16).  fp32 operands are centred, scaled fp16 pairs "
+                             "hi + lo.  192 < D <= 768: Gram and gradient are ONE fp16 product each (hi x hi): every sum the tile kernels "
+                             "accumulate carries Q = E + t (second order in t ~ 2/D), and the part linear in t is closed form from "
+                             "third moments and Z^T Z - Y^T Y (DESIGN 4.1g/4.1h; a device flag falls back to the three-product E-form "
+                             "when t can leave the polynomial range) -- executed = algorithmic.  768 < D <= 1024: Gram two products, "
+                             "gradient one.  D <= 192: three and three.  Of the 10 N^2 D algorithmic flops 6 are Gram and 4 gradient; "
+                             "`frac` is algorithmic / peak, `frac_executed` counts the executed products (upper bound: the symmetric "
+                             "y-y launch executes half of its share; the fp32 GEMMs of the closed form are outside the timed kernels)"}
     if mode == "bf16":
         return {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None, "traffic": None,

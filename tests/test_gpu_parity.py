@@ -486,6 +486,26 @@ def test_rccl_collectives_single_rank_group():
             b.backward()
             assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 * abs(float(b.detach()))
             assert relerr(za.grad.float().cpu().numpy(), zb.grad.float().cpu().numpy()) <= tol
+        # the staged form (sharded preparation): asynchronous RCCL all-gathers INTO workspace regions (bytes), the
+        # all-reduce of the D x D matrices, the one scalar read-back that decides about the lo images
+        import transformer_vae_amd.distributed as tdist
+        keep = tdist.STAGED_MIN_ELEMENTS
+        tdist.STAGED_MIN_ELEMENTS = 0
+        try:
+            for (n, d), dtype, tol in (((640, 300), torch.float32, 1e-6), ((1100, 768), torch.float32, 1e-6), ((1500, 77), torch.float32, 1e-6),
+                                       ((640, 1024), torch.float32, 1e-6), ((640, 384), torch.bfloat16, BF16_TOL)):
+                z = torch.from_numpy(np.tanh(rs.standard_normal((n, d))).astype(np.float32)).to(dev()).to(dtype)
+                y = torch.from_numpy(rs.standard_normal((n, d)).astype(np.float32)).to(dev()).to(dtype)
+                za = z.clone().requires_grad_(True)
+                a = sharded_mmd_reg_loss(za, y, batch_size_local=64, n_latents=10)
+                a.backward()
+                zb = z.clone().requires_grad_(True)
+                b = F.mmd_reg_loss(zb, y, batch_size=64, n_latents=10)
+                b.backward()
+                assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 * abs(float(b.detach())), (n, d, dtype)
+                assert relerr(za.grad.float().cpu().numpy(), zb.grad.float().cpu().numpy()) <= tol, (n, d, dtype)
+        finally:
+            tdist.STAGED_MIN_ELEMENTS = keep
     finally:
         dist.destroy_process_group()
 

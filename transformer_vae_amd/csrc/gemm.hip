@@ -64,7 +64,10 @@ struct GemmArgs {
 // that no load sits behind a bounds check -- was 0-20 % SLOWER at the BASELINE cfg2/cfg3 shapes.)
 template <typename T, bool KMAJOR, int BKT>
 __device__ __forceinline__ void tile_load(float v[BKT / 16][4], const T* __restrict__ P, const RowMap& map, int r0, int R,
-                                          int k0, int kend, bool vec, int tid, const float* __restrict__ sub = nullptr) {
+                                          int k0, int kend, bool vec, int tid, const float* __restrict__ sub = nullptr,
+                                          const float* ksub = nullptr) {
+    // sub: GemmDesc::a_sub / b_sub of a row-major operand (indexed by k: re-read per tile).  ksub: the same for a k-major
+    // operand, whose four contiguous indices are the same for every tile of a thread -- hoisted into registers by the caller
 #pragma unroll
     for (int j = 0; j < BKT / 16; ++j) {
         const int q = tid + 256 * j;
@@ -89,9 +92,9 @@ __device__ __forceinline__ void tile_load(float v[BKT / 16][4], const T* __restr
                 const T* p = P + map(k) + r;
                 const int nv = min(4, R - r);
                 if (vec && nv == 4) load4_vec(p, v[j]); else load4_guard(p, nv, v[j]);
-                if (sub) {
+                if (ksub) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (e < nv) v[j][e] -= sub[r + e];
+                    for (int e = 0; e < 4; ++e) if (e < nv) v[j][e] -= ksub[e];
                 }
             }
         }
@@ -150,16 +153,31 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& a, int bx, int by
     const bool csum = CSUM && a.csum != nullptr;
     const int nb_real = csum ? a.Nb : a.N;                            // columns B really has
     float ra[BKT / 16][4], rb[BKT / 16][4];
-    tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, kbeg, kend, a.vecA, tid, a.a_sub);
-    tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, kbeg, kend, a.vecB, tid, a.b_sub);
+    float asub[4] = {0.f, 0.f, 0.f, 0.f}, bsub[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* aks = nullptr;
+    const float* bks = nullptr;
+    if (A_KMAJOR && a.a_sub) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int r = m0 + (tid & 15) * 4 + e; asub[e] = r < a.M ? a.a_sub[r] : 0.f; }
+        aks = asub;
+    }
+    if (B_KMAJOR && a.b_sub) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int r = n0 + (tid & 15) * 4 + e; bsub[e] = r < nb_real ? a.b_sub[r] : 0.f; }
+        bks = bsub;
+    }
+    const float* asr = A_KMAJOR ? nullptr : a.a_sub;
+    const float* bsr = B_KMAJOR ? nullptr : a.b_sub;
+    tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, kbeg, kend, a.vecA, tid, asr, aks);
+    tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, kbeg, kend, a.vecB, tid, bsr, bks);
     if (CSUM && csum) tile_ones<BKT>(rb, n0, a.Nb, kbeg, kend, tid);
     for (int k0 = kbeg; k0 < kend; k0 += BKT) {
         tile_store<A_KMAJOR, BKT>(As, ra, tid);
         tile_store<B_KMAJOR, BKT>(Bs, rb, tid);
         __syncthreads();
         if (k0 + BKT < kend) {      // next tile's loads fly during this tile's MFMAs
-            tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, k0 + BKT, kend, a.vecA, tid, a.a_sub);
-            tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, k0 + BKT, kend, a.vecB, tid, a.b_sub);
+            tile_load<T, A_KMAJOR, BKT>(ra, A, a.amap, m0, a.M, k0 + BKT, kend, a.vecA, tid, asr, aks);
+            tile_load<T, B_KMAJOR, BKT>(rb, B, a.bmap, n0, nb_real, k0 + BKT, kend, a.vecB, tid, bsr, bks);
             if (CSUM && csum) tile_ones<BKT>(rb, n0, a.Nb, k0 + BKT, kend, tid);
         }
 #pragma unroll
