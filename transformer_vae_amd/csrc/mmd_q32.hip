@@ -53,8 +53,14 @@ struct Q32Lds {
     static_assert(XCH_ONE_B >= (8 + 4 * 64) * 8, "final reduction reuses an exchange buffer");
 };
 
+#ifndef TVAE_Q32_LAG
+#define TVAE_Q32_LAG 4        // k-steps by which local row block 1 leads block 0 in the Gram (>= NK: one block after the other)
+#endif
+#ifndef TVAE_Q32_SUM_LAG
+#define TVAE_Q32_SUM_LAG 16
+#endif
 #ifndef TVAE_Q32_DIAG
-#define TVAE_Q32_DIAG 0       // timing diagnostics (results are wrong): 1 no Q work, 2 no Gram operand reads, 3 no foreign stores, 4 same tile every step
+#define TVAE_Q32_DIAG 0       // timing diagnostics (results are wrong): 1 no Q work, 2 no Gram operand reads, 3 no foreign stores, 4 same tile every step, 5 no finishing of the partial sums, 6 no transposed gradient operand reads
 #endif
 
 
@@ -227,9 +233,29 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
     // ------------------------------------------------------------------------------------------------------------------
 #define Q32_PIN() __builtin_amdgcn_sched_barrier(0)
 
-    constexpr int NS = 2 * NK;                                // Gram slots: pass 0 = local row block 1 (all foreign), pass 1 = block 0
-    constexpr int GD = 6, RING = 8;                           // Gram operand reads run GD slots ahead, in a ring of RING registers
-    static_assert(NS >= 8 && GD < RING && 4 * KB >= 8, "slot schedule");
+    // Gram slots.  Each k-step's operand is read from LDS ONCE and feeds both row blocks (the kernel is bound by the LDS
+    // pipe -- 260 KB per step per CU against 128 B per clock, DESIGN 4.1h -- and reading it once per block was 48 KB of
+    // that).  Local row block 1 (all foreign: its partial sums leave through LDS) runs LAG k-steps ahead of block 0, so
+    // that it completes -- and its stores go out -- 2 LAG - 1 slots before the interval's last matrix instruction:
+    //     (1,0) .. (1,LAG-1) | (0,0) (1,LAG) (0,1) (1,LAG+1) ... | (0,NK-LAG) .. (0,NK-1)
+    constexpr int NS = 2 * NK;
+    constexpr int LAG = NK < TVAE_Q32_LAG ? NK : TVAE_Q32_LAG;
+    constexpr int GD = 6, RING = LAG + 3 < NK ? LAG + 4 : NK; // operand reads run GD slots ahead of their first use, in a ring of RING registers
+    struct Sched {
+        static constexpr int lb(int s) { return s < LAG ? 1 : (s < 2 * NK - LAG ? ((s - LAG) & 1) : 0); }
+        static constexpr int ks(int s) { return s < LAG ? s : (s < 2 * NK - LAG ? (((s - LAG) & 1) ? LAG + (s - LAG) / 2 : (s - LAG) / 2) : s - NK); }
+        static constexpr int first(int k) { return k < LAG ? k : LAG + 2 * (k - LAG) + 1; }         // slot of block 1's use of k-step k
+        static constexpr int last(int k) { return k < NK - LAG ? LAG + 2 * k : NK + k; }             // ... and of block 0's
+        static constexpr int rd(int k) { return first(k) - GD; }                                     // slot behind which it is read (< 0: end of the previous interval)
+        static constexpr bool ring_ok() {
+            for (int k = 0; k + RING < NK; ++k)
+                if (rd(k + RING) < last(k)) return false;
+            return true;
+        }
+        static constexpr int pre() { int n = 0; for (int k = 0; k < NK; ++k) n += rd(k) < 0 ? 1 : 0; return n; }
+    };
+    static_assert(NS >= 8 && 4 * KB >= 8 && Sched::ring_ok(), "slot schedule");
+    constexpr int PRE = Sched::pre();                         // operands read at the end of the previous interval
     // Per-lane LDS addresses of a buffer's operands, worked out ONCE per interval and pinned in registers (hipcc otherwise
     // re-adds buffer base + lane offset in front of every read: 46 vector additions per step, 8 cycles each on a lone wave)
     struct Bases { int g[2]; int t[2][2]; int xw[3]; int xr; int nr; int ew; int er; };
@@ -306,10 +332,9 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
 
     // Gram operand of slot t of the step in buffer b (pass t / NK, k-step t % NK).  Pass 0 reads a block for the first time:
     // counted wait for its LDS-DMA (`slack` = DMA instructions issued after this step's)
-    auto gram_rd = [&](const Bases& B, int t, int slack) __attribute__((always_inline)) {
-        const int ks = t % NK;
-        if (t < NK && (ks & 1) == 0) wait_vmcnt_n(2 * (KB - 1 - (ks >> 1)) + slack);
-        ab[t % RING] = Q32_LDS(const q_f16x8, B.g[ks & 1] + 2048 * (ks >> 1));
+    auto gram_rd = [&](const Bases& B, int ks, int slack) __attribute__((always_inline)) {
+        if ((ks & 1) == 0) wait_vmcnt_n(2 * (KB - 1 - (ks >> 1)) + slack);
+        ab[ks % RING] = Q32_LDS(const q_f16x8, B.g[ks & 1] + 2048 * (ks >> 1));
     };
 
     // gradient operands: transposed reads of block blk (read rd = 2 kk + j), the Q pieces
@@ -323,23 +348,23 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
     constexpr int FW0 = (20 + FH - 2) / (FH - 1), FW1 = (20 + 4 * KB - FH - 3) / (4 * KB - FH - 2);      // finishing operations per slot
     static_assert(1 + 19 / FW0 < FH && FH + 2 + 19 / FW1 < 4 * KB, "finishing schedule");
 
-    // Q work of a step, as 40 single operations: element el = idx / 5, Horner step idx % 5 of
-    //     esc Q(x) = x^2 (k0 + k1 x + k2 x^2 + k3 x^3),   k = esc (1/2, 1/6, 1/24, 1/120),   esc = +-2^12
+    // Q work of a step, as 32 single operations: Horner steps of
+    //     esc Q(x) = x^2 (k0 + k1 x + k2 x^2),   k = esc (1/2, 1/6, 1/24),   esc = +-2^12
     // (second order, no cancellation).  The kernel only runs when the device flag bounds every t of the call by 1/16
-    // (mmd.hip, QFlag): the next term, x^4 / 720, is below 4e-8 of Q there and 1e-13 of it at the t ~ 2 / D of the shapes
-    // that matter.  The fp16 scale of the Q pieces and the sign of prior columns (s_p = -1) ride in the coefficients, which
-    // are scalars picked per step: no multiply, no sign flip afterwards.
+    // (mmd.hip, QFlag): the next term, x^3 / 120, is below 4e-6 of Q there -- 1.3e-7 of E, Q being t / 2 of it -- and 3e-10 of
+    // Q at the t ~ 2 / D of the shapes that matter.  The fp16 scale of the Q pieces and the sign of prior columns (s_p = -1)
+    // ride in the coefficients, which are scalars picked per step: no multiply, no sign flip afterwards.
+    constexpr int QOPS = 32;
     float pe[8];
-    float kq0 = 0.f, kq1 = 0.f, kq2 = 0.f, kq3 = 0.f;
+    float kq0 = 0.f, kq1 = 0.f, kq2 = 0.f;
     // OPERATION-major order (idx = 8 op + el): neighbouring instructions belong to different elements -- a dependent vector
-    // instruction on a lone wave costs ~13 cycles against 8 for an independent one (the first slot version ran the five
+    // instruction on a lone wave costs ~13 cycles against 8 for an independent one (the first slot version ran the
     // Horner steps of one element back to back: 84 cycles per slot instead of 40)
     auto e_op = [&](int idx) __attribute__((always_inline)) {
         const int el = idx % 8, op = idx / 8;
         const float x = xv[el];
-        if (op == 0) pe[el] = fmaf(kq3, x, kq2);
-        else if (op == 1) pe[el] = fmaf(pe[el], x, kq1);
-        else if (op == 2) pe[el] = fmaf(pe[el], x, kq0);
+        if (op == 0) pe[el] = fmaf(kq2, x, kq1);
+        else if (op == 1) pe[el] = fmaf(pe[el], x, kq0);
         else pe[el] = pe[el] * x;
     };
 
@@ -354,18 +379,18 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
         constexpr bool WITH_E = true;
         constexpr int slack = PF_SLACK;                       // behind this step's LDS-DMA: only the L2 prefetches of the last interval
         constexpr int ESL = NS - 4;                           // Q operations spread over slots 0 .. ESL-1 (two per slot at D = 768)
-        constexpr int EW = (40 + ESL - 1) / ESL;
+        constexpr int EW = (QOPS + ESL - 1) / ESL;
         {
             // sign by integer arithmetic on the (wave-uniform) set index: stays in scalar registers
             const unsigned sbit = (unsigned)__builtin_amdgcn_readfirstlane(x_set) << 31;
             kq0 = __uint_as_float(__float_as_uint(SPLIT_E_SCALE / 2.f) ^ sbit);
             kq1 = __uint_as_float(__float_as_uint(SPLIT_E_SCALE / 6.f) ^ sbit);
             kq2 = __uint_as_float(__float_as_uint(SPLIT_E_SCALE / 24.f) ^ sbit);
-            kq3 = __uint_as_float(__float_as_uint(SPLIT_E_SCALE / 120.f) ^ sbit);
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int lb = s < NK ? 1 : 0, ks = s % NK;
+            constexpr int S1_DONE = Sched::first(NK - 1);     // slot of block 1's last matrix instruction
+            const int lb = Sched::lb(s), ks = Sched::ks(s);
             if (s == 0 || s == NK) {
                 // pin the gradient accumulators to their accumulator registers through the Gram: left alone, hipcc parks two
                 // of the blocks in vector registers for this phase and gives their registers to S (64 moves per step)
@@ -374,16 +399,18 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
 #pragma unroll
                     for (int y = 0; y < 2; ++y) asm volatile("" : "+a"(acc[x][y]));
             }
-            S[lb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[s % RING], zreg[lb][ks], ks == 0 ? zero16 : S[lb], 0, 0, 0);
+            S[lb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[ks % RING], zreg[lb][ks], ks == 0 ? zero16 : S[lb], 0, 0, 0);
             Q32_PIN();
 #if TVAE_Q32_DIAG != 2
-            if (s + GD < NS) gram_rd(Bg, s + GD, slack);
+#pragma unroll
+            for (int k2 = 0; k2 < NK; ++k2)
+                if (Sched::rd(k2) == s) gram_rd(Bg, k2, slack);
 #endif
             if constexpr (WITH_E && TVAE_Q32_DIAG != 1) {
                 if (s < ESL) {
 #pragma unroll
                     for (int i = 0; i < EW; ++i)
-                        if (EW * s + i < 40) e_op(EW * s + i);
+                        if (EW * s + i < QOPS) e_op(EW * s + i);
                 } else if (s == ESL) {
                     // this lane's eight entries belong to ONE row: their sum serves the Q sums and the row sum.  pe = s_p 2^12 Q
                     float es = ((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7]));
@@ -399,11 +426,11 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
                     Q32_LDS(q_f16x8, Bt.ew) = ev;
                 }
             }
-            // the foreign row block is complete after slot NK - 1: its four stores two slots later (matrix-pipe latency)
+            // the foreign row block is complete after slot S1_DONE: its four stores two slots later (matrix-pipe latency)
 #if TVAE_Q32_DIAG != 3
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (s == (NK + 2 + i < NS - 1 ? NK + 2 + i : NS - 1)) xch_store(Bg, i >> 1, i & 1);
+                if (s == (S1_DONE + 2 + i < NS - 1 ? S1_DONE + 2 + i : NS - 1)) xch_store(Bg, i >> 1, i & 1);
 #endif
             if constexpr (WITH_E) {
                 // the gradient's first operand reads (wave-private step data: legal ahead of the barrier), two per slot
@@ -440,23 +467,27 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
             const q_f16x8 A = __builtin_bit_cast(q_f16x8, __builtin_shufflevector(gh[blk][kk][0], gh[blk][kk][1], 0, 1, 2, 3, 4, 5, 6, 7));
             acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bq[kk][rbk], acc[blk][rbk], 0, 0, 0);
             Q32_PIN();
+#if TVAE_Q32_DIAG != 6
             if (blk + TDB < KB) grad_rd(Bt, blk + TDB, s & 3);
+#endif
             // block blk - 1 is dead (its matrix instructions are issued, their operand reads have completed): refill it
             if ((s & 3) == 0 && blk >= 1) dma_block(Xn, b, blk - 1);
             // the 20 finishing operations of registers 0-3 in slots 1 .. H-1, the second quad's partial sums fetched in slot H,
             // its 20 operations in slots H+2 .. (two per slot at D = 768)
 #pragma unroll
+#if TVAE_Q32_DIAG != 5
             for (int i = 0; i < 20; ++i) {
                 if (s == 1 + i / FW0) xch_finish_op(0, i);
                 if (s == FH + 2 + i / FW1) xch_finish_op(1, i);
             }
+#endif
             if (s == FH) xch_fetch(Bg, 1);
             Q32_PIN();
         }
         dma_block(Xn, b, KB - 1);
         // slots 0 .. GD-1 of the next interval's Gram: the step just refilled into this buffer
 #pragma unroll
-        for (int t = 0; t < GD; ++t) gram_rd(Bt, t, 0);
+        for (int t = 0; t < PRE; ++t) gram_rd(Bt, t, 0);
         Q32_PIN();
         l2_prefetch(Xpf);
         Q32_PIN();
@@ -504,7 +535,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
             {
                 const Bases B0 = grad_bases(0);
 #pragma unroll
-                for (int t = 0; t < GD; ++t) gram_rd(B0, t, 0);
+                for (int t = 0; t < PRE; ++t) gram_rd(B0, t, 0);
             }
             wait_vmcnt<0>();                                  // buffer 1 is read transposed at the end of phase A without a counted wait
             Q32_PIN();
@@ -601,7 +632,28 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
     if (__builtin_amdgcn_readfirstlane((int)*a.qflag) == 0) return;
     using L = Q32SumLds<KB>;
     constexpr int P = 32, SW = 32 * KB, DPAD = 4 * SW, NK = 2 * KB, NS = 2 * NK, SPB = 64 / P;
-    constexpr int GD = 3, RING = 4;
+    // every k-step's operand is read ONCE for both row blocks; block 1 runs LAG k-steps ahead (see mmd_q32_kernel)
+    constexpr int LAG = NK < TVAE_Q32_SUM_LAG ? NK : TVAE_Q32_SUM_LAG;
+    constexpr int GD = 3, RING = LAG + 1 < NK ? LAG + 2 : NK;
+    struct Sched {
+        static constexpr int lb(int s) { return s < LAG ? 1 : (s < 2 * NK - LAG ? ((s - LAG) & 1) : 0); }
+        static constexpr int ks(int s) { return s < LAG ? s : (s < 2 * NK - LAG ? (((s - LAG) & 1) ? LAG + (s - LAG) / 2 : (s - LAG) / 2) : s - NK); }
+        static constexpr int first(int k) { return k < LAG ? k : LAG + 2 * (k - LAG) + 1; }
+        static constexpr int last(int k) { return k < NK - LAG ? LAG + 2 * k : NK + k; }
+        static constexpr int rd(int k) { return first(k) - GD; }
+        static constexpr bool ring_ok() {
+            for (int k = 0; k + RING < NK; ++k)
+                if (rd(k + RING) < last(k)) return false;
+            return true;
+        }
+        static constexpr int pre() { int n = 0; for (int k = 0; k < NK; ++k) n += rd(k) < 0 ? 1 : 0; return n; }
+        // the last operand read that waits on this step's own LDS-DMA (even k-steps do): the interval's own DMA goes out behind it
+        static constexpr int rd_last() { const int r = rd(NK - 2); return r < 0 ? 0 : r; }
+        // refill of block blk: behind block 1's use of its second k-step (the operand reads have returned) and behind rd_last
+        static constexpr int refill(int blk) { const int a = first(2 * blk + 1), b = rd_last() + 1 + blk; return a > b ? a : b; }
+    };
+    static_assert(Sched::ring_ok() && Sched::refill(KB - 1) < 2 * NK, "slot schedule");
+    constexpr int PRE = Sched::pre();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -725,12 +777,21 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
     float xv[8], fsv[8], fcn[8], pe[8];
     f32x4 part[2][3], cn[2];
     double sum0 = 0.0, sum1 = 0.0;
+    float fq0 = 0.f, fq1 = 0.f;
+    auto flush_sums = [&]() __attribute__((always_inline)) {
+        sum0 += (double)(row_valid ? fq0 : 0.f); sum1 += (double)(row_valid ? fq1 : 0.f);
+        fq0 = 0.f; fq1 = 0.f;
+    };
 
     // one interval: Gram of the step in buffer b (tile k + 1), refilled behind pass 1 with step Xr (norms into ring slot
     // ring_r); the partial sums of step k (exchange buffer xb_rd, norms in ring slot ring_e, meta m) are finished and summed
     // between the matrix instructions; the partial sums of the Gram go to exchange buffer xb_wr.
     // idx list of the vector work, operation-major over the eight entries of a lane:
-    //   [0, 40)  finishing (op 0: norm term; 1-3: own + three remote partials; 4: x)      [40, 80)  Q (five Horner steps)
+    //   [0, 40)  finishing (op 0: norm term; 1-3: own + three remote partials; 4: x)
+    //   [40, 72) Q(x) = y (1/2 + x/6 + y/24), y = x^2, SUMMED as it is formed: four fused-multiply-add chains of two entries
+    //            (only the sum over the lane's entries is needed here; truncation as in mmd_q32_kernel)
+    constexpr int VOPS = 72;
+    float e4[4];
     auto v_op = [&](int idx) __attribute__((always_inline)) {
         if (idx < 40) {
             const int r = idx & 7, op = idx >> 3;
@@ -742,18 +803,18 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
         } else {
             const int el = (idx - 40) & 7, op = (idx - 40) >> 3;
             const float x = xv[el];
-            if (op == 0) pe[el] = fmaf(1.f / 120.f, x, 1.f / 24.f);
-            else if (op == 1) pe[el] = fmaf(pe[el], x, 1.f / 6.f);
-            else if (op == 2) pe[el] = fmaf(pe[el], x, 0.5f);
-            else pe[el] = pe[el] * x;
+            if (op == 0) pe[el] = fmaf(1.f / 6.f, x, 0.5f);
+            else if (op == 1) fcn[el] = x * x;
+            else if (op == 2) pe[el] = fmaf(1.f / 24.f, fcn[el], pe[el]);
+            else e4[el & 3] = el < 4 ? pe[el] * fcn[el] : fmaf(pe[el], fcn[el], e4[el & 3]);
         }
     };
     // the own partial S[0][0..7] of step k is consumed by op 1 above; the Gram of step k + 1 overwrites S[0] in pass 1 (slots
     // NK ..): op 1 has to be placed before slot NK -- the list puts idx 8 .. 15 into slots <= 5
     constexpr int V0 = 0;                                     // first slot with vector work (the partial sums' LDS round trip before it)
     constexpr int VSL = NS - 3 - V0;                          // vector work spread over slots V0 .. V0 + VSL - 1
-    constexpr int VW = (80 + VSL - 1) / VSL;
-    static_assert(V0 + (15 / VW) < NK, "the own partial sums are read before pass 1 overwrites them");
+    constexpr int VW = (VOPS + VSL - 1) / VSL;
+    static_assert(V0 + (15 / VW) < LAG, "the own partial sums are read before block 0's first matrix instruction overwrites them");
     auto interval = [&](int b, const Src& Xr, int ring_r, int xb_rd, int xb_wr, int ring_e, const Meta& m, bool with_e, int slack) __attribute__((always_inline)) {
         const int gb0 = lds0 + (int)xbuf_byte(b);
         int gbase[2] = {gb0 + gram_off[0], gb0 + gram_off[1]};
@@ -761,10 +822,9 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
         int xw[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xw[c] = xw_off[c] + xb_wr * L::XCH_ONE_B; asm volatile("" : "+v"(xw[c])); }
-        auto gram_rd = [&](int t) __attribute__((always_inline)) {
-            const int ks = t % NK;
-            if (t < NK && (ks & 1) == 0) wait_vmcnt_n(2 * (KB - 1 - (ks >> 1)) + slack);
-            ab[t % RING] = Q32_LDS(const q_f16x8, gbase[ks & 1] + 2048 * (ks >> 1));
+        auto gram_rd = [&](int ks) __attribute__((always_inline)) {
+            if ((ks & 1) == 0) wait_vmcnt_n(2 * (KB - 1 - (ks >> 1)) + slack);
+            ab[ks % RING] = Q32_LDS(const q_f16x8, gbase[ks & 1] + 2048 * (ks >> 1));
         };
         {
             const int xr = xr_off + xb_rd * L::XCH_ONE_B, nr = nr_off + ring_e * 4 * 64 * 4;
@@ -776,32 +836,38 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
             }
         }
 #pragma unroll
-        for (int t = 0; t < GD; ++t) gram_rd(t);
+        for (int t = 0; t < PRE; ++t) gram_rd(t);
         Q32_PIN();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int lb = s < NK ? 1 : 0, ks = s % NK;
-            S[lb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[s % RING], zreg[lb][ks], ks == 0 ? zero16 : S[lb], 0, 0, 0);
+            constexpr int S1_DONE = Sched::first(NK - 1);
+            const int lb = Sched::lb(s), ks = Sched::ks(s);
+            S[lb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[ks % RING], zreg[lb][ks], ks == 0 ? zero16 : S[lb], 0, 0, 0);
             Q32_PIN();
-            if (s + GD < NS) gram_rd(s + GD);
-            if (s == NK - 1) stage_norms(Xr, ring_r);      // behind pass 0's last counted wait: the counts above stay exact
+#pragma unroll
+            for (int k2 = 0; k2 < NK; ++k2)
+                if (Sched::rd(k2) == s) gram_rd(k2);
+            if (s == Sched::rd_last()) stage_norms(Xr, ring_r);      // behind the last counted wait: the counts above stay exact
             if (s >= V0 && s < V0 + VSL) {
 #pragma unroll
                 for (int i = 0; i < VW; ++i)
-                    if (VW * (s - V0) + i < 80) v_op(VW * (s - V0) + i);
+                    if (VW * (s - V0) + i < VOPS) v_op(VW * (s - V0) + i);
             } else if (s == V0 + VSL) {
-                float es = ((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7]));
-                es = (row_valid && with_e) ? es * m.w : 0.f;
-                sum0 += (double)(m.set ? 0.f : es);
-                sum1 += (double)(m.set ? es : 0.f);
+                // fp32 partials over eight intervals, then fp64 (flush_sums); the weight and the set are wave-uniform
+                // (interval -1 finishes whatever the exchange buffer held: a select, not a zero weight, keeps a NaN out)
+                const float es = with_e ? (e4[0] + e4[1]) + (e4[2] + e4[3]) : 0.f;
+                fq0 = fmaf(es, m.set ? 0.f : m.w, fq0);
+                fq1 = fmaf(es, m.set ? m.w : 0.f, fq1);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (s == (NK + 2 + i < NS - 1 ? NK + 2 + i : NS - 1))
+                if (s == (S1_DONE + 2 + i < NS - 1 ? S1_DONE + 2 + i : NS - 1))
                     Q32_LDS(f32x4, xw[i >> 1] + (i & 1) * 1024) = f32x4{S[1][8 * (i >> 1) + 4 * (i & 1)], S[1][8 * (i >> 1) + 4 * (i & 1) + 1],
                                                                           S[1][8 * (i >> 1) + 4 * (i & 1) + 2], S[1][8 * (i >> 1) + 4 * (i & 1) + 3]};
-            // pass 1 has read both k-steps of block blk: refill it with the same block of step Xr
-            if (s >= NK && (ks & 1) == 1) dma_block(Xr, b, ks >> 1);
+            // both k-steps of block blk are in registers: refill it with the same block of step Xr
+#pragma unroll
+            for (int blk = 0; blk < KB; ++blk)
+                if (Sched::refill(blk) == s) dma_block(Xr, b, blk);
             Q32_PIN();
         }
 #pragma unroll
@@ -820,7 +886,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
 #pragma unroll
         for (int s = 0; s < KB; ++s) dma_block(X1, 1, s);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { xv[r] = 0.f; pe[r] = 0.f; fsv[r] = 0.f; fcn[r] = 0.f; }
+        for (int r = 0; r < 8; ++r) { xv[r] = 0.f; pe[r] = 0.f; fsv[r] = 0.f; fcn[r] = 0.f; e4[r & 3] = 0.f; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; }
         wait_vmcnt<0>();
@@ -836,7 +902,9 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if ((k & 7) == 7) flush_sums();
         }
+        flush_sums();
         // the zero padding points of this workgroup's column range: out of the sums in closed form (see mmd_q32_kernel)
         {
             float npad[2] = {0.f, 0.f};
@@ -849,10 +917,8 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
             }
             if ((npad[0] != 0.f || npad[1] != 0.f) && row_valid) {
                 const float x = rnx;
-                float p = fmaf(1.f / 120.f, x, 1.f / 24.f);
-                p = fmaf(p, x, 1.f / 6.f);
-                p = fmaf(p, x, 0.5f);
-                const double qp = (double)((p * x) * x);
+                const float y = x * x;
+                const double qp = (double)(fmaf(1.f / 24.f, y, fmaf(1.f / 6.f, x, 0.5f)) * y);
                 sum0 -= (double)npad[0] * qp;
                 sum1 -= (double)npad[1] * qp;
             }
