@@ -566,21 +566,25 @@ __device__ __forceinline__ void prep_store(TC* dst, long long idx, long long lo_
 __host__ __device__ constexpr int rec_a_doubles(int DPAD) { return 2 * DPAD + 2; }
 __host__ __device__ constexpr int rec_b_doubles(int DPAD) { return 4 * DPAD + 4; }
 
+struct QFlag { unsigned on; unsigned pad; double az, ay; };      // az, ay: sums of squared norms over all points
+
 __device__ __forceinline__ float wave_maxf(float m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     return m;
 }
 
-// stage A, first half: per-wave column sums and maxima of rows_per_wave source rows (plain stores, no atomics).
+// stage A, first half: per-WORKGROUP column sums and maxima of 4 x rows_per_wave source rows (plain stores, no atomics;
+// the four waves' sums meet in LDS, so the second half reads a quarter of the partials).
 // fp64 from the first add: the mean-shift term of the gradient, sum z - sum y, comes from these sums, and under a common
 // offset (both+50, tests/test_gpu_r3.py) fp32 partial sums of ~64 rows already cost 1.5e-5 of the gradient
 __global__ __launch_bounds__(256) void mmd_stats_kernel(const float* __restrict__ z, const float* __restrict__ y, int n_src, int D,
                                                         int DPAD, int rows_per_wave, int nwaves, double* __restrict__ colpart,
                                                         float* __restrict__ amaxpart) {
-    const int lane = threadIdx.x & 63;
-    const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wg >= nwaves) return;
+    __shared__ double red[3][1024];
+    __shared__ float redm[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wg = blockIdx.x * 4 + wave;
     const int set = blockIdx.y;
     const float* __restrict__ src = set ? y : z;
     const int NJ = (DPAD + 63) / 64;
@@ -588,24 +592,54 @@ __global__ __launch_bounds__(256) void mmd_stats_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < 16; ++j) csum[j] = 0.0;
     float m = 0.f;
-    const int r0 = wg * rows_per_wave, r1 = min(n_src, r0 + rows_per_wave);
-    for (int row = r0; row < r1; ++row) {
+    const int r0 = wg * rows_per_wave, r1 = wg < nwaves ? min(n_src, r0 + rows_per_wave) : r0;
+    if (NJ <= 4) {
+        // narrow rows: four rows at a time, every load issued before the first use (see mmd_prep_kernel)
+        for (int row = r0; row < r1; row += 4) {
+            float v[4][4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int c = lane + 64 * j;
-            if (j < NJ && c < D) {
-                const float v = src[(long long)row * D + c];
-                csum[j] += (double)v;
-                m = fmaxf(m, fabsf(v));
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = lane + 64 * j;
+                    const bool ok = j < NJ && c < D && row + u < r1;
+                    const float t = src[ok ? (long long)(row + u) * D + c : 0ll];
+                    v[u][j] = ok ? t : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { csum[j] += (double)v[u][j]; m = fmaxf(m, fabsf(v[u][j])); }
+        }
+    } else {
+        for (int row = r0; row < r1; ++row) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = lane + 64 * j;
+                if (j < NJ && c < D) {
+                    const float v = src[(long long)row * D + c];
+                    csum[j] += (double)v;
+                    m = fmaxf(m, fabsf(v));
+                }
             }
         }
     }
-    double* cp = colpart + ((long long)set * nwaves + wg) * DPAD;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (j < NJ && lane + 64 * j < DPAD) cp[lane + 64 * j] = csum[j];
     m = wave_maxf(m);
-    if (lane == 0) amaxpart[set * nwaves + wg] = m;
+    if (lane == 0) redm[wave] = m;
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < NJ) red[wave - 1][lane + 64 * j] = csum[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double* cp = colpart + ((long long)set * gridDim.x + blockIdx.x) * DPAD;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < NJ && lane + 64 * j < DPAD)
+                cp[lane + 64 * j] = ((csum[j] + red[0][lane + 64 * j]) + red[1][lane + 64 * j]) + red[2][lane + 64 * j];
+        if (lane == 0) amaxpart[set * gridDim.x + blockIdx.x] = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    }
 }
 
 // stage A, second half: fp64 sums of the partials in a fixed order, one workgroup per 64 columns; workgroup 0 also
@@ -776,11 +810,17 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const T* __restrict__ z, 
 // stage B, the record: fp64 sums of the per-wave partials in a fixed order -- over every wave (rec_all) and over the
 // waves of the owned rows (rec_loc).  Workgroups 0 .. ncb - 1 take 64 columns each; workgroup ncb sums the squared
 // norms of the source rows [g0, g1) and of the owned rows [lo, hi) and finds the largest.
+// One process (`shift` non-null): every record is complete here, so the kernel also emits what mmd_closed_kernel would --
+// shift, m3, the dot products (one partial triple per column workgroup: dots[3 ncb]) and the Q-form flag -- and that
+// launch is skipped.
 __global__ __launch_bounds__(1024) void mmd_recb_kernel(const float* __restrict__ colpart, const float* __restrict__ colpart3,
                                                         int nwaves, int nw0, int nw1, int DPAD, const float* __restrict__ zn,
                                                         const float* __restrict__ yn, int g0, int g1, int lo, int hi, int ncb,
-                                                        double* __restrict__ rec_all, double* __restrict__ rec_loc) {
+                                                        double* __restrict__ rec_all, double* __restrict__ rec_loc,
+                                                        const double* __restrict__ rec_a, int D, float* __restrict__ shift,
+                                                        float* __restrict__ m3, double* __restrict__ dots, QFlag* __restrict__ qflag) {
     __shared__ double red[4][16][64];
+    __shared__ double prod[3][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     if ((int)blockIdx.x == ncb) {
         double az = 0.0, ay = 0.0, azl = 0.0, ayl = 0.0;
@@ -809,6 +849,12 @@ __global__ __launch_bounds__(1024) void mmd_recb_kernel(const float* __restrict_
             double* rl = rec_loc + 4 * DPAD;
             ra[0] = t[0]; ra[1] = t[1]; ra[2] = m; ra[3] = 0.0;
             rl[0] = t[2]; rl[1] = t[3]; rl[2] = ml; rl[3] = 0.0;
+            if (shift && qflag) {      // as mmd_closed_kernel
+                const float bound = 4.f * (float)m / ((float)D * (float)D);
+                qflag->on = (bound < 0.5f * EM1_POLY_MAX) ? 1u : 0u;
+                qflag->pad = 0u;
+                qflag->az = t[0]; qflag->ay = t[1];
+            }
         }
         return;
     }
@@ -835,6 +881,19 @@ __global__ __launch_bounds__(1024) void mmd_recb_kernel(const float* __restrict_
             for (int k = 0; k < 16; ++k) { t[0] += red[0][k][cx]; t[1] += red[1][k][cx]; t[2] += red[2][k][cx]; t[3] += red[3][k][cx]; }
             rec_all[(2 * pass) * DPAD + c] = t[0]; rec_all[(2 * pass + 1) * DPAD + c] = t[1];
             rec_loc[(2 * pass) * DPAD + c] = t[2]; rec_loc[(2 * pass + 1) * DPAD + c] = t[3];
+            if (shift && pass == 0) shift[c] = rec_a ? (float)(rec_a[c] - rec_a[DPAD + c]) : (float)(t[0] - t[1]);
+            if (shift && pass == 1 && m3 && part) m3[c] = (float)(t[0] - t[1]);
+            if (pass == 0) { prod[0][cx] = t[2] * t[0]; prod[1][cx] = t[2] * t[1]; prod[2][cx] = t[3] * t[1]; }
+        } else if (ry == 0 && pass == 0) {
+            prod[0][cx] = 0.0; prod[1][cx] = 0.0; prod[2][cx] = 0.0;
+        }
+        if (shift && pass == 0) {
+            __syncthreads();
+            if (threadIdx.x < 3) {
+                double d = 0.0;
+                for (int k = 0; k < 64; ++k) d += prod[threadIdx.x][k];
+                dots[blockIdx.x * 3 + threadIdx.x] = d;
+            }
         }
     }
 }
@@ -846,7 +905,6 @@ __global__ __launch_bounds__(1024) void mmd_recb_kernel(const float* __restrict_
 // For the shapes that matter t ~ 2 / D, so Q ~ t^2 / 2 is ~1e-3 of E and ONE fp16 product carries the tile kernel's share of
 // the gradient at the accuracy of the fp32 kernel.  Valid while every t of the call is below the
 // polynomial range: the closed-form kernel bounds t by 4 max |.|^2 / D^2 on the device, and tile kernel and finalize read it.
-struct QFlag { unsigned on; unsigned pad; double az, ay; };      // az, ay: sums of squared norms over all points
 
 // M2 = Z^T Z - Y^T Y (in place over the first) with shift appended as column D: row r of the D x (D + 1) matrix the
 // row product below multiplies by, so that column D of its result is shift . z_k
@@ -905,7 +963,7 @@ struct FinalArgs {
     void* d_z;
     const unsigned* split_amax;   // split kernels: the gradient slabs carry 2^12 s G (split_scales); else null
     // closed-form linear part: squared norms of all points, the records, the column-moment dot products
-    const float* zn; int n_total; const double* dots; const double* rec_all; const double* rec_loc;
+    const float* zn; int n_total; const double* dots; int ndots; const double* rec_all; const double* rec_loc;
     // Q-form gradient (null: off): the flag, m3, and P = Z_rows [M2 | shift] (row stride ldP, column D = shift . z_k)
     const QFlag* qflag; const float* m3; const float* P; int ldP;
 };
@@ -939,9 +997,11 @@ __global__ __launch_bounds__(256) void mmd_finalize_kernel(FinalArgs f) {
             const double az = f.rec_all[4 * f.DPAD], ay = f.rec_all[4 * f.DPAD + 1];
             const double azl = f.rec_loc[4 * f.DPAD], ayl = f.rec_loc[4 * f.DPAD + 1];
             const double N = (double)f.n_total, nl = (double)f.n_rows, inv = 1.0 / ((double)f.D * (double)f.D);
-            const double szz = qzz - (N * azl + nl * az - 2.0 * f.dots[0]) * inv;
-            const double szy = qzy - (N * azl + nl * ay - 2.0 * f.dots[1]) * inv;
-            const double syy = qyy - (N * ayl + nl * ay - 2.0 * f.dots[2]) * inv;
+            double dzz = 0.0, dzy = 0.0, dyy = 0.0;
+            for (int k = 0; k < f.ndots; ++k) { dzz += f.dots[3 * k]; dzy += f.dots[3 * k + 1]; dyy += f.dots[3 * k + 2]; }
+            const double szz = qzz - (N * azl + nl * az - 2.0 * dzz) * inv;
+            const double szy = qzy - (N * azl + nl * ay - 2.0 * dzy) * inv;
+            const double syy = qyy - (N * ayl + nl * ay - 2.0 * dyy) * inv;
             f.sums3[0] = szz; f.sums3[1] = szy; f.sums3[2] = syy;
             if (f.loss) *f.loss = (float)(f.loss_scale * (syy + szz - 2.0 * szy));
         }
@@ -1151,7 +1211,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     p->off_yn = take((int64_t)p->n_pad * 4);
     p->off_colpart = take((int64_t)2 * p->nwaves * p->DPAD * (p->split ? 8 : 4));      // split: stage A's fp64 partials first
     p->off_shift = take((int64_t)p->DPAD * 4);
-    p->off_dots = take(3 * 8);
+    p->off_dots = take((int64_t)((p->DPAD + 63) / 64) * 3 * 8);
     p->off_sums = take((int64_t)(2 * p->row_blocks + p->row_blocks_g) * p->col_splits * 2 * 8);
     p->off_rowsum = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * 8 : 0);
     p->off_grad = take(want_grad ? (int64_t)p->col_splits * p->n_rows_pad * p->DPAD * 4 : 0);
@@ -1355,7 +1415,7 @@ int stage_stats(const Call& c, const void* z_src, const void* y_src, hipStream_t
                        (int)c.n_src, (int)c.D, p.DPAD, c.rpw, nw, colpart, amaxpart);
     TVAE_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(mmd_stats_final_kernel, dim3((p.DPAD + 63) / 64), dim3(1024), 0, s, (const double*)colpart,
-                       (const float*)amaxpart, nw, p.DPAD, c.at<double>(p.off_reca));
+                       (const float*)amaxpart, (nw + 3) / 4, p.DPAD, c.at<double>(p.off_reca));
     TVAE_CHECK_HIP(hipGetLastError());
     return TVAE_OK;
 }
@@ -1388,9 +1448,13 @@ int stage_prep(const Call& c, const void* z_src, const void* y_src, hipStream_t 
 #undef TVAE_PREP
     TVAE_CHECK_HIP(hipGetLastError());
     const int ncb = (p.DPAD + 63) / 64;
+    // one process: the records are complete, the closed-form pieces come out of the same launch
+    const bool whole = c.n_src == c.n_total;
     hipLaunchKernelGGL(mmd_recb_kernel, dim3(ncb + 1), dim3(1024), 0, s, (const float*)colpart, (const float*)colpart3, c.nwaves,
                        c.nw0, c.nw1, p.DPAD, (const float*)zn, (const float*)yn, (int)c.src_row0, (int)(c.src_row0 + c.n_src),
-                       c.lo, c.hi, ncb, c.at<double>(p.off_recb), c.at<double>(p.off_recb_loc));
+                       c.lo, c.hi, ncb, c.at<double>(p.off_recb), c.at<double>(p.off_recb_loc), rec_a, (int)c.D,
+                       whole ? c.at<float>(p.off_shift) : nullptr, p.qform ? c.at<float>(p.off_m3) : nullptr,
+                       c.at<double>(p.off_dots), (p.qform || p.qsum) ? c.at<QFlag>(p.off_qflag) : nullptr);
     TVAE_CHECK_HIP(hipGetLastError());
     if (p.qform) {
         float* m2z = c.at<float>(p.off_m2);
@@ -1456,7 +1520,9 @@ int stage_tiles(const Call& c, const void* z_rows, double* sums3, float* loss, d
     // the y-y problem as a launch of its own (the others put both problems into one launch)
     const bool yy_alone = d_z && !p.n16 && !(!p.bf16_tiles && !p.narrow64 && p.WAVES == 1);
 
+    const bool whole = c.n_src == c.n_total;          // one process: mmd_recb_kernel has emitted the closed-form pieces already
     if (phase & 1) {
+        if (!whole)
         hipLaunchKernelGGL(mmd_closed_kernel, dim3(1), dim3(1024), 0, s, (const double*)c.at<double>(p.off_recb),
                            (const double*)c.at<double>(p.off_recb_loc), (const double*)(c.centred() ? c.at<double>(p.off_reca) : nullptr),
                            (int)D, p.DPAD, shift, m3, dots, qflag);
@@ -1522,7 +1588,7 @@ int stage_tiles(const Call& c, const void* z_rows, double* sums3, float* loss, d
     f.D = (int)D; f.DPAD = p.DPAD; f.sums3 = sums3; f.loss = loss; f.loss_scale = loss_scale; f.grad_scale = grad_scale;
     f.d_z = d_z;
     f.split_amax = split_amax;
-    f.zn = zn; f.n_total = (int)n_total; f.dots = dots;
+    f.zn = zn; f.n_total = (int)n_total; f.dots = dots; f.ndots = whole ? (p.DPAD + 63) / 64 : 1;
     f.rec_all = c.at<double>(p.off_recb); f.rec_loc = c.at<double>(p.off_recb_loc);
     f.qflag = p.qform ? qflag : nullptr; f.m3 = m3; f.P = pmat; f.ldP = p.ldq;
     long long fb = d_z ? ((long long)n_rows * D + 255) / 256 : 1;
