@@ -59,7 +59,11 @@ def _worker(rank, world, port, case, out, staged=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    import traceback
+    # a rank that dies must not leave the other one (and the test) waiting: short collective timeout, and every failure
+    # travels to the parent through the queue
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
         B, S, d, n, L = CASES[case]
         h, prior, g0 = _inputs(case)
@@ -73,8 +77,14 @@ def _worker(rank, world, port, case, out, staged=False):
             dist.all_reduce(t)
             grads[k] = t.numpy()
         out.put((rank, reg, dh, z, grads))
+    except BaseException:
+        out.put((rank, "error", traceback.format_exc(), None, None))
+        raise
     finally:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 def _free_port():
@@ -96,9 +106,16 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(case, staged):
     procs = [ctx.Process(target=_worker, args=(r, world, port, case, q, staged)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    try:
+        res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == "error"), f"rank {r[0]} failed:\n{r[2]}"
     for p in procs:
-        p.join(timeout=60)
         assert p.exitcode == 0
     B, S, d, n, L = CASES[case]
     h, prior, g0 = _inputs(case)

@@ -357,7 +357,10 @@ __global__ __launch_bounds__(256) void gemm_reduce_pair_kernel(GemmPairArgs q) {
 void choose_split_bk(int M, int N, int K, int bk, int* splits, int* k_per_split) {
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int s = 1;
-    if (tiles < 256 && K > (bk == BK ? 256 : bk)) {
+    // ... and the same for launches of up to a few workgroups per CU whose K is in the thousands (the D x D products of the
+    // MMD's closed form and the weight gradients at D, d_model = 1024: 256 tiles, K = the row count -- one workgroup per CU
+    // walking K = 65 536 alone ran at a sixth of the split form's rate, BASELINE cfg5)
+    if ((tiles < 256 && K > (bk == BK ? 256 : bk)) || (tiles < TVAE_SPLIT_TARGET && K >= 8192)) {
         // enough workgroups for ~8 per CU: with one 32x32 accumulator per wave the kernel hides its global
         // loads through occupancy (2-3 workgroups per CU left the weight-gradient products at 30 % MFMA-busy)
         s = (int)((TVAE_SPLIT_TARGET + tiles - 1) / tiles);
