@@ -149,9 +149,12 @@ int tvae_decode_bwd(const void* d_recon, const void* latent, const void* Wd,
  *   d_z    (n_rows, D) out, nullable: grad_scale * sum-form gradient for the local rows,
  *          complete (needs no exchange):  pass grad_scale = 4 n / (B N^2 D^2) for
  *          d reg_loss / d latent  (SURVEY.md 8a).  Written in `dtype`.
- * Any D: fused tile kernels up to 1024 (TVAE_F32 inputs: two or three fp16 hi/lo products per fp32 product on the 16-bit
- * matrix cores, D <= 192 from 1024 points on; TVAE_BF16 inputs wider than 192: one bf16 product; TVAE_F32_STRICT and
- * everything else: fp32-input MFMA), strip-wise through the projection GEMM beyond.  n_total < 2^30. */
+ * Any D: fused tile kernels up to 1024.  TVAE_F32 inputs run on the 16-bit matrix cores as centred, power-of-two-scaled fp16
+ * pairs hi + lo: ONE fp16 product per fp32 product for 192 < D <= 768 (the kernels sum the second-order part Q = E + t and the
+ * part linear in t is closed form; a device flag falls back to three products when t can leave the polynomial's range), two
+ * (Gram) and one (gradient) for 768 < D <= 1024, three for D <= 192 from 1024 points on.  TVAE_BF16 inputs wider than 192: one
+ * bf16 product.  TVAE_F32_STRICT and everything else: fp32-input MFMA.  D > 1024: strip-wise through the projection GEMM.
+ * n_total < 2^30. */
 int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad);
 /* Same, for the dtype the call will be made with (TVAE_F32 / TVAE_BF16).  tvae_mmd_workspace_bytes covers
  * either; bf16 calls with large column sets use one gradient slab per ~24 MB column chunk (up to 32 GiB in all),
