@@ -1528,6 +1528,9 @@ int stage_tiles(const Call& c, const void* z_rows, double* sums3, float* loss, d
                            (int)D, p.DPAD, shift, m3, dots, qflag);
         TVAE_CHECK_HIP(hipGetLastError());
         if (yy_alone && phase == 1) {      // (phase 3: behind the gradient launch, inside the profiling bracket)
+            // a sharded caller's bracket opens here and closes behind the gradient launch of its phase-2 call
+            if (g_prof_start) TVAE_CHECK_HIP(hipEventRecord(g_prof_start, s));
+            g_prof_start = nullptr;
             a.problem_base = 1; a.sums_base = nwg0; a.row_blocks = p.row_blocks;
             TVAE_PROPAGATE(launch_tiles<false>(p, a, nwg1, s));    // y rows: sum only
         }

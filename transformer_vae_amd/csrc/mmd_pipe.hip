@@ -1026,7 +1026,7 @@ int launch_pipe(const MmdArgs& a, int nblocks, hipStream_t s) {
         if (a.qflag != nullptr) {          // the pair: exactly one of the two does the work (QFlag)
 #if TVAE_Q32
             return launch_mmd_q32(KB, a, nblocks, s);      // round 3: one-product, 32-point, all-32x32x16 Q-form kernel (mmd_q32.hip)
-#endif
+#else       // -DTVAE_Q32=0: round 2's Q-form instance of this file (two-product Gram, 16-point steps, tile ring)
             static PerDeviceOnce once_q;
             TVAE_CHECK_HIP(per_device_once(once_q, [] {
                 return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_pipe_kernel<KB, SPLIT, true>),
@@ -1034,6 +1034,7 @@ int launch_pipe(const MmdArgs& a, int nblocks, hipStream_t s) {
             }));
             hipLaunchKernelGGL((mmd_pipe_kernel<KB, SPLIT, true>), dim3(nblocks), dim3(256), lds_bytes, s, a);
             TVAE_CHECK_HIP(hipGetLastError());
+#endif
         }
     }
     return TVAE_OK;
