@@ -172,8 +172,11 @@ class EncoderDecoderVAE(nn.Module):
             if m is not None and (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks
                                   or m._backward_pre_hooks):
                 return False
-        if any(p.dtype != h.dtype for p in self.parameters()):
-            return False
+        # the stock pair's parameters, named (the types are exact above; walking self.parameters() costs 11 us per eager step)
+        norm = getattr(dec, "norm", None)
+        for m in (enc.token_to_latent, dec.latent_to_token, norm):
+            if m is not None and (m.weight.dtype != h.dtype or (m.bias is not None and m.bias.dtype != h.dtype)):
+                return False
         if self._global_scope_active():
             return False
         return True
