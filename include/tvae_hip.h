@@ -141,9 +141,12 @@ int tvae_decode_bwd(const void* d_recon, const void* latent, const void* Wd,
  * kernel matrices against ALL n_total columns (single GPU: row_offset 0, n_rows =
  * n_total).  z_all / y_all hold all n_total latent / prior rows (after the
  * all-gather), both (n_total, D), same dtype.
- *   sums3  double[3] out: sum of E over (local z rows x all z), (local z rows x all y),
- *          (local y rows x all y).  Adding sums3 over a partition of the rows gives the
- *          global sums:  MMD = (S_yy + S_zz - 2 S_zy) / n_total^2.
+ *   sums3  double[3] out: this call's share of the sums of E over (z rows x all z), (z rows x all y),
+ *          (y rows x all y).  Adding sums3 over a partition of the rows into EQUAL blocks (every call
+ *          the same n_rows, row_offset a multiple of it; or one call for everything) gives the global
+ *          sums:  MMD = (S_yy + S_zz - 2 S_zy) / n_total^2.  (The y-y share of a call is not simply
+ *          "its rows x all columns": symmetric pairs of row blocks are split between the calls that own
+ *          them, and all calls of a partition must decide alike whether to -- equal blocks do.)
  *   loss   float out, nullable: loss_scale * (S_yy + S_zz - 2 S_zy) of THIS call's rows
  *          (single GPU: pass loss_scale = n_tokens / (B * n_total^2) to get reg_loss)
  *   d_z    (n_rows, D) out, nullable: grad_scale * sum-form gradient for the local rows,

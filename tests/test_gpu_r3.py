@@ -262,3 +262,39 @@ def test_staged_entry_points_equal_the_one_call_form(shape):
             gy = g[D * ldq:].view(D, ldq)[:, :D].double()
             for got, want in ((gz, zc.T @ zc), (gy, yc.T @ yc)):
                 assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("n_loc,D,kind", [(752, 192, "strict"), (752, 512, "strict"), (736, 768, "f32"), (736, 1024, "f32"), (752, 77, "f32"),
+                                          (736, 512, "bf16"), (100, 64, "strict"), (1000, 300, "f32")])
+def test_row_blocks_of_an_equal_ragged_partition_add_up(n_loc, D, kind):
+    """Three equal row blocks whose size is not a whole number of 32- / 64-row blocks while the LAST block's offset is: the
+    symmetric y-y enumeration splits pairs of row blocks between the calls that own them, so all calls must decide alike
+    whether to use it (until round 3 the last block did and the others did not: y-y sum off by 6e-7, tools/fuzz_gpu.py)."""
+    from transformer_vae_amd import _lib
+    from transformer_vae_amd import functional as F
+    world, n_total = 3, 3 * n_loc
+    gen = torch.Generator(device=dev()).manual_seed(n_loc + D)
+    z = torch.tanh(torch.randn((n_total, D), generator=gen, device=dev())) + 0.25
+    y = torch.randn((n_total, D), generator=gen, device=dev())
+    if kind == "bf16":
+        z, y = z.bfloat16(), y.bfloat16()
+    code = {"f32": _lib.TVAE_F32, "bf16": _lib.TVAE_BF16, "strict": _lib.TVAE_F32_STRICT}[kind]
+    lib = _lib.lib()
+
+    def call(lo, rows):
+        ws = F._workspace(lib.tvae_mmd_workspace_bytes_for(n_total, rows, D, 0, code), dev())
+        s3 = torch.empty(3, dtype=torch.float64, device=dev())
+        _lib.check(lib.tvae_mmd_fwd_bwd(z.data_ptr(), y.data_ptr(), n_total, lo, rows, D, code, s3.data_ptr(), None, 1.0, None, 1.0,
+                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "mmd")
+        return s3
+
+    whole = call(0, n_total)
+    parts = sum(call(r * n_loc, n_loc) for r in range(world))
+    z64, y64 = z.double(), y.double()
+    inv = 1.0 / float(D * D)
+    nz, ny = (z64 * z64).sum(1), (y64 * y64).sum(1)
+    E = lambda a, na, b, nb: torch.expm1(-((na[:, None] + nb[None, :] - 2.0 * (a @ b.T)) * inv).clamp_min(0)).sum()
+    ref = torch.stack([E(z64, nz, z64, nz), E(z64, nz, y64, ny), E(y64, ny, y64, ny)])
+    tol = 1e-3 if kind == "bf16" else 2e-8          # of each sum (the MMD is a 1e-3-class difference of them)
+    for got in (whole, parts):
+        assert float(((got - ref).abs() / ref.abs()).max()) <= tol, (got.tolist(), ref.tolist())

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as T  # noqa: E402
+import test_gpu_r3 as R3  # noqa: E402
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -55,6 +56,12 @@ for i in range(count):
     lo = int(rs.randint(0, N))
     hi = int(rs.randint(lo + 1, N + 1))
     attempt("block", T.test_random_row_blocks_against_fp64_oracle, N, D, lo, hi)
+    # the three-stage (row-sharded) entry points against the one-call form and fp64: odd rank counts, ragged row counts
+    world = int(rs.choice([2, 3, 4, 5, 8]))
+    n_loc = int(rs.randint(1, 900))
+    Ds = int(rs.choice([3, 16, 64, 77, 130, 192, 193, 256, 300, 384, 400, 512, 640, 768, 769, 1000, 1024]))
+    kind = str(rs.choice(["f32", "f32", "strict", "bf16"]))
+    attempt("staged", R3.test_staged_entry_points_equal_the_one_call_form, (world, world * n_loc, Ds, kind))
     if i % 10 == 0:
         print(f"[{i}] ran {ran} failures {len(fails)}", flush=True)
 print(f"done: ran {ran}, failures {len(fails)}")

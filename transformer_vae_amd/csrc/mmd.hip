@@ -1510,7 +1510,14 @@ int stage_tiles(const Call& c, const void* z_rows, double* sums3, float* loss, d
     a.sp_major = (p.sync_epochs > 0 || p.sp_major) ? 1 : 0;     // a resident set then shares ONE column range
     a.sync_ctr = nullptr; a.sync_epochs = p.sync_epochs; a.sync_group = p.sync_group; a.launch_blocks = 0;
     const int sym_rows = p.n16 ? 16 * p.RT : ((p.narrow64 || p.pipe_sum) ? 64 : ROWS_PER_WG);      // row block of the symmetric y-y enumeration
-    a.sym = (row_offset % sym_rows == 0 && (n_rows % sym_rows == 0 || row_offset + n_rows == n_total)) ? 1 : 0;
+    // The symmetric enumeration shares the pairs {I, J} of row blocks between the calls that own I and J (mmd_tile_body),
+    // so EVERY call of a partition has to make the same choice.  The rule is therefore one that all blocks of an EQUAL
+    // partition answer alike: the whole problem in one call, or a block of whole sym_rows-row blocks that tiles
+    // [0, n_total).  (Until round 3 a ragged LAST block qualified on its own: with three ranks of 752 rows the last one took
+    // its symmetric share while the other two summed all of theirs -- y-y sum off by 6e-7, found by tools/fuzz_gpu.py.)
+    const bool one_call = row_offset == 0 && n_rows == n_total;
+    const bool equal_block = row_offset % sym_rows == 0 && n_rows % sym_rows == 0 && n_total % n_rows == 0 && row_offset % n_rows == 0;
+    a.sym = (one_call || equal_block) ? 1 : 0;
     a.wg_sums = c.at<double>(p.off_sums);
     a.wg_rowsum = c.at<double>(p.off_rowsum);
     a.wg_grad = c.at<float>(p.off_grad);
