@@ -83,6 +83,9 @@ struct Bf16Lds {
 // QF (split gradient launches): the Q-form instance of mmd_pipe.hip / DESIGN 4.1g -- gradient and row sums carry
 // Q = E + t in ONE fp16 product, the lo images of columns and E are neither fetched nor formed.  A launch pair; the
 // device-side flag picks the instance that runs.
+#ifndef TVAE_QF_GRAM_PRODUCTS
+#define TVAE_QF_GRAM_PRODUCTS 1     // Gram products of the Q-form instance: its sums carry Q = E + t, which tolerates the hi x hi Gram
+#endif
 template <int KB, int RT, bool GRAD, bool SPLIT, bool QF = false>
 __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
     static_assert(!QF || (GRAD && SPLIT && TVAE_GRAM_PRODUCTS == 2), "Q-form: split gradient launches with the two-product Gram");
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
     const bf16* rows = reinterpret_cast<const bf16*>(a.cols[problem]) + (long long)a.row_offset * DPAD;
     const float* rnorm = a.cnorm[problem] + a.row_offset;
     const bf16* rows_lo = SPLIT ? reinterpret_cast<const bf16*>(a.cols_lo[problem]) + (long long)a.row_offset * DPAD : rows;
-    bf16x8_t zreg[RT][KB], zlo[SPLIT ? RT : 1][SPLIT ? KB : 1];
+    constexpr bool ROW_LO = SPLIT && !(QF && TVAE_QF_GRAM_PRODUCTS == 1);      // the Gram's second product: row side lo
+    bf16x8_t zreg[RT][KB], zlo[ROW_LO ? RT : 1][ROW_LO ? KB : 1];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         const int row = i0 + 16 * t + i16;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
         for (int s = 0; s < KB; ++s) {
             if (row < a.n_rows) zreg[t][s] = *reinterpret_cast<const bf16x8_t*>(zp + 32 * s);
             else zreg[t][s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            if constexpr (SPLIT) {
+            if constexpr (ROW_LO) {
                 if (row < a.n_rows) zlo[t][s] = *reinterpret_cast<const bf16x8_t*>(zl + 32 * s);
                 else zlo[t][s] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
             }
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
 #pragma unroll
         for (int s = 0; s < KB; ++s) {
             asm volatile("" : "+v"(zreg[t][s]));
-            if constexpr (SPLIT) asm volatile("" : "+v"(zlo[t][s]));
+            if constexpr (ROW_LO) asm volatile("" : "+v"(zlo[t][s]));
         }
 #pragma unroll
     for (int j = 0; j < TPW; ++j) asm volatile("" : "+v"(rn[j]));
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
             for (int t = 0; t < RT; ++t) {
                 S[0][t] = mfma16<SPLIT>(ab[s][0], zreg[t][s], S[0][t]);
                 S[1][t] = mfma16<SPLIT>(ab[s][1], zreg[t][s], S[1][t]);
-                if constexpr (SPLIT) {
+                if constexpr (ROW_LO) {
                     S[0][t] = mfma16<SPLIT>(ab[s][0], zlo[t][s], S[0][t]);
                     S[1][t] = mfma16<SPLIT>(ab[s][1], zlo[t][s], S[1][t]);
 #if TVAE_GRAM_PRODUCTS == 3
