@@ -5,7 +5,7 @@ set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../transformer_vae_amd/csrc"
 OUT=../variants; mkdir -p $OUT/obj_$NAME
-for f in capi gemm rowops mmd mmd_bf16 mmd_pipe mmd_q32 mmd_narrow mmd_n16 mmd_wide aux small_step; do
+for f in capi gemm rowops mmd mmd_bf16 mmd_pipe mmd_q32 gram16 mmd_narrow mmd_n16 mmd_wide aux small_step; do
   # only the files the flags can touch are recompiled; the rest are the product objects
   if grep -q "TVAE_" <<< "$*" && grep -qE "$(echo "$*" | grep -oE 'TVAE_[A-Z_0-9]+' | paste -sd'|')" $f.hip; then
     EXTRA=""; [ $f = mmd_pipe ] && EXTRA="-fno-slp-vectorize"; [ $f = mmd_q32 ] && EXTRA="-fno-slp-vectorize -mllvm -pragma-unroll-threshold=65536"      # as the Makefile

@@ -1236,7 +1236,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     p->off_p = take(p->qform ? (int64_t)n_rows * p->ldq * 4 : 0);
     int64_t gs_floats = 0;
     if (p->qform) {
-        gs_floats = gemm_slab_floats((int)D, (int)D, (int)n_total);
+        gs_floats = gram16_slab_floats(p->DPAD, n_total);
         const int64_t g2 = gemm_slab_floats((int)n_rows, (int)D + 1, (int)D);
         if (g2 > gs_floats) gs_floats = g2;
     }
@@ -1457,19 +1457,13 @@ int stage_prep(const Call& c, const void* z_src, const void* y_src, hipStream_t 
                        c.at<double>(p.off_dots), (p.qform || p.qsum) ? c.at<QFlag>(p.off_qflag) : nullptr);
     TVAE_CHECK_HIP(hipGetLastError());
     if (p.qform) {
+        // Z'^T Z' and Y'^T Y' of the source rows, straight from the images just written (gram16.hip)
         float* m2z = c.at<float>(p.off_m2);
         float* m2y = m2z + (long long)c.D * p.ldq;
-        GemmDesc g{};
-        g.bias = nullptr; g.epilogue = EPI_NONE; g.dtype = TVAE_F32; g.colsum_out = nullptr;
-        g.M = (int)c.D; g.N = (int)c.D; g.K = (int)c.n_src;
-        g.a_kmajor = true; g.b_kmajor = true;
-        g.amap = dense_rows(c.D); g.bmap = dense_rows(c.D); g.cmap = dense_rows(p.ldq);
-        g.slab = c.at<float>(p.off_gslab); g.slab_floats = gemm_slab_floats((int)c.D, (int)c.D, (int)c.n_src);
-        g.a_sub = mu; g.b_sub = mu;
-        g.A = z_src; g.B = z_src; g.C = m2z;
-        TVAE_PROPAGATE(gemm_launch(g, s));
-        g.A = y_src; g.B = y_src; g.C = m2y;
-        TVAE_PROPAGATE(gemm_launch(g, s));
+        float* gslab = c.at<float>(p.off_gslab);
+        const int64_t gfloats = gram16_slab_floats(p.DPAD, c.n_total);
+        TVAE_PROPAGATE(gram16_launch(zp, lo_off, c.src_row0, c.n_src, p.DPAD, c.D, p.ldq, amax, m2z, gslab, gfloats, s));
+        TVAE_PROPAGATE(gram16_launch(yp, lo_off, c.src_row0, c.n_src, p.DPAD, c.D, p.ldq, amax, m2y, gslab, gfloats, s));
     }
     return TVAE_OK;
 }

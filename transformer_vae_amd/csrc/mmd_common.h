@@ -165,6 +165,11 @@ int launch_mmd_pipe(bool grad, bool split, int kb, const MmdArgs& a, int nblocks
 // Q-form member of the split gradient launch pair: one fp16 product, 32-point steps, 32x32x16 everywhere (mmd_q32.hip); kb = 2..6
 int launch_mmd_q32(int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 int launch_mmd_q32_sum(int kb, const MmdArgs& a, int nblocks, hipStream_t s);
+// D x D second moments of the rows [row0, row0 + n_rows) of a split-fp16 image on the 16-bit matrix cores (gram16.hip):
+// C (row stride ld) = sum x x^T with the image's scale undone (amax_bits: the scale word of the call)
+int64_t gram16_slab_floats(int64_t DPAD, int64_t n_rows);
+int gram16_launch(const void* img_hi, long long lo_off, int64_t row0, int64_t n_rows, int64_t DPAD, int64_t D, int64_t ld,
+                  const unsigned* amax_bits, float* C, float* slab, int64_t slab_floats, hipStream_t s);
 // fp32 kernel for narrow latents, 64 rows per single-wave workgroup (mmd_narrow.hip); nb = padded dimension / 16 (1..5)
 int launch_mmd_narrow(bool grad, int nb, const MmdArgs& a, int nblocks, hipStream_t s);
 // split-fp16 kernel for narrow latents, one wave per workgroup (mmd_n16.hip); kbn = padded dimension / 32 (1..6).
