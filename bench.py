@@ -84,9 +84,9 @@ def mmd_roofline(mode, L, achieved, kern_ms, launches, traffic=None):
     if mode == "split":
         # fp16 products per fp32 product.  192 < L <= 768 (mmd_q32.hip): ONE for the Gram and ONE for the gradient -- both sums
         # carry Q = E + t, the part linear in t is closed form, so executed = algorithmic.  768 < L <= 1024:
-        # the same in the gradient launch (the 32-row kernel's Q-form instance), two Gram products in its sum-only launch.  Narrow latents (mmd_n16.hip): three and three.  6 of the 10 algorithmic flops are Gram, 4 gradient
+        # the same on the 32-row kernel's Q-form instances.  Narrow latents (mmd_n16.hip): three and three.  6 of the 10 algorithmic flops are Gram, 4 gradient
         if L > 192:
-            gram_p, grad_p = 1, 1      # (768 < L <= 1024: the gradient launch; its sum-only launch still forms two Gram products)
+            gram_p, grad_p = 1, 1
         else:
             gram_p, grad_p = 3, 3
         split_exec = (6 * gram_p + 4 * grad_p) / 10.0
@@ -103,8 +103,8 @@ def mmd_roofline(mode, L, achieved, kern_ms, launches, traffic=None):
                              "hi + lo.  192 < D <= 768: Gram and gradient are ONE fp16 product each (hi x hi): every sum the tile kernels "
                              "accumulate carries Q = E + t (second order in t ~ 2/D), and the part linear in t is closed form from "
                              "third moments and Z^T Z - Y^T Y (DESIGN 4.1g/4.1h; a device flag falls back to the three-product E-form "
-                             "when t can leave the polynomial range) -- executed = algorithmic.  768 < D <= 1024: the same in the gradient launch; two Gram "
-                             "products in the sum-only launch.  D <= 192: three and three.  Of the 10 N^2 D algorithmic flops 6 are Gram and 4 gradient; "
+                             "when t can leave the polynomial range) -- executed = algorithmic (768 < D <= 1024: the same, on the 32-row kernels)."
+                             "  D <= 192: three and three.  Of the 10 N^2 D algorithmic flops 6 are Gram and 4 gradient; "
                              "`frac` is algorithmic / peak, `frac_executed` counts the executed products (upper bound: the symmetric "
                              "y-y launch executes half of its share; the fp32 GEMMs of the closed form are outside the timed kernels)"}
     if mode == "bf16":

@@ -154,8 +154,8 @@ int tvae_decode_bwd(const void* d_recon, const void* latent, const void* Wd,
  *          d reg_loss / d latent  (SURVEY.md 8a).  Written in `dtype`.
  * Any D: fused tile kernels up to 1024.  TVAE_F32 inputs run on the 16-bit matrix cores as centred, power-of-two-scaled fp16
  * pairs hi + lo: ONE fp16 product per fp32 product for 192 < D <= 768 (the kernels sum the second-order part Q = E + t and the
- * part linear in t is closed form; a device flag falls back to three products when t can leave the polynomial's range), the same
- * in the gradient launch for 768 < D <= 1024 (two Gram products in its sum-only launch), three for D <= 192 from 1024 points on.  TVAE_BF16 inputs wider than 192: one
+ * part linear in t is closed form; a device flag falls back to two / three products when t can leave the polynomial's range), the
+ * same for 768 < D <= 1024 on the 32-row kernels, three for D <= 192 from 1024 points on.  TVAE_BF16 inputs wider than 192: one
  * bf16 product.  TVAE_F32_STRICT and everything else: fp32-input MFMA.  D > 1024: strip-wise through the projection GEMM.
  * n_total < 2^30. */
 int64_t tvae_mmd_workspace_bytes(int64_t n_total, int64_t n_rows, int64_t D, int want_grad);

@@ -88,8 +88,10 @@ struct Bf16Lds {
 #endif
 template <int KB, int RT, bool GRAD, bool SPLIT, bool QF = false>
 __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
-    static_assert(!QF || (GRAD && SPLIT && TVAE_GRAM_PRODUCTS == 2), "Q-form: split gradient launches with the two-product Gram");
-    if constexpr (GRAD && SPLIT) {
+    static_assert(!QF || (SPLIT && TVAE_GRAM_PRODUCTS == 2), "Q-form: split launches with the two-product Gram");
+    // launch pairs under the device flag (mmd.hip, QFlag): the gradient launch always; the sum-only launch of the 32-row
+    // kernel's widths (KB >= 7), whose QF member differs from the other only in forming ONE Gram product
+    if constexpr (SPLIT && (GRAD || (RT == 2 && KB >= 7))) {
         if (a.qflag != nullptr && (__builtin_amdgcn_readfirstlane((int)*a.qflag) != 0) != QF) return;
     }
     using L = Bf16Lds<KB, RT, GRAD, SPLIT>;
@@ -561,7 +563,7 @@ int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
     const int lds_launch = lds_bytes + debug_lds_pad() > lds_attr ? lds_attr : lds_bytes + debug_lds_pad();
     hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD, SPLIT>), dim3(nblocks), dim3(256), lds_launch, s, a);
     TVAE_CHECK_HIP(hipGetLastError());
-    if constexpr (GRAD && SPLIT) {
+    if constexpr (SPLIT && (GRAD || (RT == 2 && KB >= 7))) {
         if (a.qflag != nullptr) {          // the pair: exactly one of the two does the work (mmd.hip, QFlag)
             if constexpr (RT == 2 && KB >= 7 && TVAE_GRAM_PRODUCTS == 2) {
                 static PerDeviceOnce once_q;
