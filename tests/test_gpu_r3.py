@@ -298,3 +298,41 @@ def test_row_blocks_of_an_equal_ragged_partition_add_up(n_loc, D, kind):
     tol = 1e-3 if kind == "bf16" else 2e-8          # of each sum (the MMD is a 1e-3-class difference of them)
     for got in (whole, parts):
         assert float(((got - ref).abs() / ref.abs()).max()) <= tol, (got.tolist(), ref.tolist())
+
+
+@pytest.mark.parametrize("world,n_loc,D,grad", [(1, 32837, 768, True), (1, 16500, 384, False), (2, 16512, 512, True), (2, 16500, 512, True),
+                                                (2, 16448, 640, True), (1, 33000, 256, False)])
+def test_sum_only_launches_on_128_row_workgroups(world, n_loc, D, grad):
+    """Sizes at which the sum-only launches of the split mode run mmd_q32_sum2_kernel (128 rows per workgroup, two halves
+    sharing each step's tile): ragged ends, the two-problem launch of a call without gradient, row blocks that are whole
+    128-row blocks (symmetric enumeration over 128-point blocks), ragged equal blocks (plain enumeration), and blocks that are
+    whole 64- but not 128-row blocks (the 64-row kernel keeps them).  The three sums against torch fp64."""
+    from transformer_vae_amd import _lib
+    from transformer_vae_amd import functional as F
+    n_total = world * n_loc
+    gen = torch.Generator(device=dev()).manual_seed(world + n_loc + D)
+    z = torch.tanh(torch.randn((n_total, D), generator=gen, device=dev())) * 0.8 + 0.1
+    y = torch.randn((n_total, D), generator=gen, device=dev())
+    lib = _lib.lib()
+    parts = torch.zeros(3, dtype=torch.float64, device=dev())
+    for r in range(world):
+        ws = F._workspace(lib.tvae_mmd_workspace_bytes_for(n_total, n_loc, D, int(grad), _lib.TVAE_F32), dev())
+        s3 = torch.empty(3, dtype=torch.float64, device=dev())
+        dz = torch.empty((n_loc, D), device=dev()) if grad else None
+        _lib.check(lib.tvae_mmd_fwd_bwd(z.data_ptr(), y.data_ptr(), n_total, r * n_loc, n_loc, D, _lib.TVAE_F32, s3.data_ptr(), None, 1.0,
+                                        dz.data_ptr() if grad else None, 1.0, ws.data_ptr(), ws.numel(),
+                                        torch.cuda.current_stream().cuda_stream), "mmd")
+        parts += s3
+        del ws
+    z64, y64 = z.double(), y.double()
+    inv = 1.0 / float(D * D)
+    nz, ny = (z64 * z64).sum(1), (y64 * y64).sum(1)
+    ref = torch.zeros(3, dtype=torch.float64, device=dev())
+    for r0 in range(0, n_total, 4096):
+        sl = slice(r0, r0 + 4096)
+        E = lambda a, na, b, nb: torch.expm1(-((na[:, None] + nb[None, :] - 2.0 * (a @ b.T)) * inv).clamp_min(0)).sum()
+        ref += torch.stack([E(z64[sl], nz[sl], z64, nz), E(z64[sl], nz[sl], y64, ny), E(y64[sl], ny[sl], y64, ny)])
+    err = ((parts - ref).abs() / ref.abs()).tolist()
+    assert max(err) <= 2e-8, (err, parts.tolist(), ref.tolist())
+    mmd, mmd_ref = float(parts[2] + parts[0] - 2.0 * parts[1]), float(ref[2] + ref[0] - 2.0 * ref[1])
+    assert abs(mmd - mmd_ref) <= 1e-6 * abs(mmd_ref), (mmd, mmd_ref)

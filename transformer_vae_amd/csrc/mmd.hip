@@ -1139,7 +1139,9 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     p->pipe = (pipe_ok && want_grad) ? 1 : 0;
     p->pipe_sum = (pipe_ok && (p->split || kPipeSumBf16)) ? 1 : 0;
     const int rows_wg = p->n16 ? mmd_n16_rows(p->NB) : ((p->narrow64 || p->pipe_sum) ? 64 : ROWS_PER_WG);
-    p->n_pad = (int)align_up(n_total, rows_wg);      // whole 32- (64-) point blocks (symmetric y-y enumeration)
+    // whole 32- (64-) point blocks (symmetric y-y enumeration); 128 for the split pipelined plans, whose sum-only launch may
+    // run 128-row workgroups over 128-point blocks (mmd_q32_sum2_kernel)
+    p->n_pad = (int)align_up(n_total, (p->split && p->pipe_sum) ? 128 : rows_wg);
     p->row_blocks = (int)((n_rows + rows_wg - 1) / rows_wg);
     p->RT = p->n16 ? rows_wg / 16 : ((p->pipe || p->pipe_sum) ? 4 : 2);
     p->row_blocks_g = p->narrow64 ? p->row_blocks : (int)((n_rows + 16 * p->RT - 1) / (16 * p->RT));
@@ -1512,6 +1514,7 @@ int stage_tiles(const Call& c, const void* z_rows, double* sums3, float* loss, d
     const bool one_call = row_offset == 0 && n_rows == n_total;
     const bool equal_block = row_offset % sym_rows == 0 && n_rows % sym_rows == 0 && n_total % n_rows == 0 && row_offset % n_rows == 0;
     a.sym = (one_call || equal_block) ? 1 : 0;
+    a.sym2 = (one_call || (equal_block && row_offset % 128 == 0 && n_rows % 128 == 0)) ? 1 : 0;
     a.wg_sums = c.at<double>(p.off_sums);
     a.wg_rowsum = c.at<double>(p.off_rowsum);
     a.wg_grad = c.at<float>(p.off_grad);

@@ -22,6 +22,7 @@ struct MmdArgs {
     unsigned* sync_ctr;      // [groups][sync_epochs] arrival counters, zeroed before the launch
     int sync_epochs, sync_group, launch_blocks;
     int sym;                 // 1: the y-y problem visits each unordered pair of 32-row blocks once (weight 2)
+    int sym2;                // the same choice for 128-row blocks (mmd_q32_sum2_kernel)
     float inv_d2;
     double* wg_sums;         // [2 * row_blocks * col_splits][2]
     double* wg_rowsum;       // [col_splits][n_rows_pad]
