@@ -93,13 +93,13 @@ def mmd_roofline(mode, L, achieved, kern_ms, launches, traffic=None):
         return {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None, "traffic": traffic,
                 "kernel": ("mmd_n16_kernel<KBN,RT,*>" if L <= 192 else
-                           "mmd_q32_kernel<KB> (gradient launch) + mmd_q32_sum_kernel<KB> (y-y sums)" if pipe else "mmd_bf16_kernel<KB,2,*,true,*> (Q-form gradient launch)"),
+                           "mmd_q32_kernel<KB> (gradient launch) + mmd_q32_sum3_kernel<KB> (y-y sums)" if pipe else "mmd_bf16_kernel<KB,2,*,true,*> (Q-form gradient launch)"),
                 "kernel_ms": kern_ms, "launches_timed": launches,
                 "products_per_fp32_product": {"gram": gram_p, "gradient": grad_p},
                 "executed_per_algorithmic": split_exec,
                 "executed_tflops": split_exec * achieved if achieved else None,
                 "frac_executed": split_exec * achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None,
-                "peak_note": "fp16 MFMA dense peak (v_mfma_f32_32x32x16_f16 / 16x16x32_f16).  fp32 operands are centred, scaled fp16 pairs "
+                "peak_note": "fp16 MFMA dense NOMINAL peak (v_mfma_f32_32x32x16_f16 / 16x16x32_f16; the bare instruction with random operands sustains 1 690 TFLOP/s = 0.68 of it at 1.61 GHz on this part: profiles/r03_mfma_power.txt).  fp32 operands are centred, scaled fp16 pairs "
                              "hi + lo.  192 < D <= 768: Gram and gradient are ONE fp16 product each (hi x hi): every sum the tile kernels "
                              "accumulate carries Q = E + t (second order in t ~ 2/D), and the part linear in t is closed form from "
                              "third moments and Z^T Z - Y^T Y (DESIGN 4.1g/4.1h; a device flag falls back to the three-product E-form "

@@ -303,8 +303,8 @@ def test_row_blocks_of_an_equal_ragged_partition_add_up(n_loc, D, kind):
 @pytest.mark.parametrize("world,n_loc,D,grad", [(1, 32837, 768, True), (1, 16500, 384, False), (2, 16512, 512, True), (2, 16500, 512, True),
                                                 (2, 16448, 640, True), (1, 33000, 256, False)])
 def test_sum_only_launches_on_128_row_workgroups(world, n_loc, D, grad):
-    """Sizes at which the sum-only launches of the split mode run mmd_q32_sum2_kernel (128 rows per workgroup, two halves
-    sharing each step's tile): ragged ends, the two-problem launch of a call without gradient, row blocks that are whole
+    """Sizes at which the sum-only launches of the split mode run mmd_q32_sum3_kernel (128 rows per workgroup, each wave
+    its 32 rows against the whole step): ragged ends, the two-problem launch of a call without gradient, row blocks that are whole
     128-row blocks (symmetric enumeration over 128-point blocks), ragged equal blocks (plain enumeration), and blocks that are
     whole 64- but not 128-row blocks (the 64-row kernel keeps them).  The three sums against torch fp64."""
     from transformer_vae_amd import _lib

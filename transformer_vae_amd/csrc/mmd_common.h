@@ -22,7 +22,7 @@ struct MmdArgs {
     unsigned* sync_ctr;      // [groups][sync_epochs] arrival counters, zeroed before the launch
     int sync_epochs, sync_group, launch_blocks;
     int sym;                 // 1: the y-y problem visits each unordered pair of 32-row blocks once (weight 2)
-    int sym2;                // the same choice for 128-row blocks (mmd_q32_sum2_kernel)
+    int sym2;                // the same choice for 128-row blocks (mmd_q32_sum3_kernel)
     float inv_d2;
     double* wg_sums;         // [2 * row_blocks * col_splits][2]
     double* wg_rowsum;       // [col_splits][n_rows_pad]
@@ -166,6 +166,8 @@ int launch_mmd_pipe(bool grad, bool split, int kb, const MmdArgs& a, int nblocks
 // Q-form member of the split gradient launch pair: one fp16 product, 32-point steps, 32x32x16 everywhere (mmd_q32.hip); kb = 2..6
 int launch_mmd_q32(int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 int launch_mmd_q32_sum(int kb, const MmdArgs& a, int nblocks, hipStream_t s);
+// its 128-row member without a K-split (mmd_q32s.hip); a: row_blocks / launch_blocks already set for 128-row workgroups
+int launch_mmd_q32_sum3(int kb, const MmdArgs& a, int nblocks, hipStream_t s);
 // D x D second moments of the rows [row0, row0 + n_rows) of a split-fp16 image on the 16-bit matrix cores (gram16.hip):
 // C (row stride ld) = sum x x^T with the image's scale undone (amax_bits: the scale word of the call)
 int64_t gram16_slab_floats(int64_t DPAD, int64_t n_rows);

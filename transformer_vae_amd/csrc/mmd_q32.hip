@@ -31,11 +31,11 @@
 #include <type_traits>
 
 #include "mmd_common.h"
+#include "mmd_q32.h"
 
 namespace tvae {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) _Float16 q_f16x8;
 typedef __attribute__((ext_vector_type(4))) short q_s16x4;
 typedef __attribute__((ext_vector_type(8))) short q_s16x8;
 
@@ -60,14 +60,13 @@ struct Q32Lds {
 #define TVAE_Q32_SUM_LAG 16
 #endif
 #ifndef TVAE_Q32_SUM_ROWS128
-#define TVAE_Q32_SUM_ROWS128 1    // sum-only launches: 128 rows per workgroup when the launch is large enough (0: always 64)
+#define TVAE_Q32_SUM_ROWS128 1    // sum-only launches: 128 rows per workgroup without a K-split (mmd_q32s.hip) when the launch is large enough (0: always this file's 64-row kernel)
 #endif
 #ifndef TVAE_Q32_DIAG
 #define TVAE_Q32_DIAG 0       // timing diagnostics (results are wrong): 1 no Q work, 2 no Gram operand reads, 3 no foreign stores, 4 same tile every step, 5 no finishing of the partial sums, 6 no transposed gradient operand reads
 #endif
 
 
-__device__ __forceinline__ int q32_swz(int q) { return (2 * (q & 1)) ^ ((q >> 1) & 1) ^ (3 * ((q >> 2) & 1)); }
 
 template <int KB>
 __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
@@ -168,7 +167,6 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
     }
     // LDS is addressed by 32-bit byte addresses that already include the base of the dynamic segment (pointer arithmetic on
     // `smem` costs one vector addition of the -- relocated, zero -- segment base per access)
-#define Q32_LDS(T, addr) (*reinterpret_cast<__attribute__((address_space(3))) T*>((unsigned)(addr)))
     const int lds0 = (int)smem_byte;
     auto tr_read = [&](int addr) __attribute__((always_inline)) -> q_s16x4 {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) q_s16x4*>((unsigned)addr));
@@ -234,7 +232,6 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
     // region per k-step / feature block: 7.24 ms at N = 32 768, D = 768; its phase timer showed 1 400 and 1 600 cycles for
     // the two 768-cycle matrix phases and 900 cycles of exchange / barrier / fetch with the matrix pipe idle.)
     // ------------------------------------------------------------------------------------------------------------------
-#define Q32_PIN() __builtin_amdgcn_sched_barrier(0)
 
     // Gram slots.  Each k-step's operand is read from LDS ONCE and feeds both row blocks (the kernel is bound by the LDS
     // pipe -- 260 KB per step per CU against 128 B per clock, DESIGN 4.1h -- and reading it once per block was 48 KB of
@@ -940,369 +937,17 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
     }
 }
 
-// The same with 128 rows per workgroup: the two 64-row halves take turns on every step's tile (half 0's Gram, then half
-// 1's, each with its own exchange and finishing exactly as above), so the column stream and its LDS-DMA are paid once
-// per 128 rows.  The sum-only launch has no gradient accumulators to make room for, and at 64 rows it waits on that stream
-// (no-refill diagnostic -27 %).  Symmetric enumeration over 128-row / 128-point blocks; the set's image is padded to whole
-// 128-point blocks (mmd.hip, make_plan).  Writes one wg_sums entry per workgroup and zeroes the other entries its 64-row
-// partner in the launch pair would have written.
-template <int KB>
-__global__ __launch_bounds__(256, 1) void mmd_q32_sum2_kernel(MmdArgs a) {
-    if (__builtin_amdgcn_readfirstlane((int)*a.qflag) == 0) return;
-    using L = Q32SumLds<KB>;
-    constexpr int P = 32, SW = 32 * KB, DPAD = 4 * SW, NK = 2 * KB, NS = 2 * NK, SPB = 128 / P;      // 128 rows per workgroup: two 64-row halves share every step's tile
-    // every k-step's operand is read ONCE for both row blocks; block 1 runs LAG k-steps ahead (see mmd_q32_kernel)
-    constexpr int LAG = NK < TVAE_Q32_SUM_LAG ? NK : TVAE_Q32_SUM_LAG;
-    constexpr int GD = 3, RING = LAG + 1 < NK ? LAG + 2 : NK;
-    struct Sched {
-        static constexpr int lb(int s) { return s < LAG ? 1 : (s < 2 * NK - LAG ? ((s - LAG) & 1) : 0); }
-        static constexpr int ks(int s) { return s < LAG ? s : (s < 2 * NK - LAG ? (((s - LAG) & 1) ? LAG + (s - LAG) / 2 : (s - LAG) / 2) : s - NK); }
-        static constexpr int first(int k) { return k < LAG ? k : LAG + 2 * (k - LAG) + 1; }
-        static constexpr int last(int k) { return k < NK - LAG ? LAG + 2 * k : NK + k; }
-        static constexpr int rd(int k) { return first(k) - GD; }
-        static constexpr bool ring_ok() {
-            for (int k = 0; k + RING < NK; ++k)
-                if (rd(k + RING) < last(k)) return false;
-            return true;
-        }
-        static constexpr int pre() { int n = 0; for (int k = 0; k < NK; ++k) n += rd(k) < 0 ? 1 : 0; return n; }
-        // the last operand read that waits on this step's own LDS-DMA (even k-steps do): the interval's own DMA goes out behind it
-        static constexpr int rd_last() { const int r = rd(NK - 2); return r < 0 ? 0 : r; }
-        // refill of block blk: behind block 1's use of its second k-step (the operand reads have returned) and behind rd_last
-        static constexpr int refill(int blk) { const int a = first(2 * blk + 1), b = rd_last() + 1 + blk; return a > b ? a : b; }
-    };
-    static_assert(Sched::ring_ok() && Sched::refill(KB - 1) < 2 * NK, "slot schedule");
-    constexpr int PRE = Sched::pre();
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* sm = reinterpret_cast<char*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wp = wave & 1;
-    const int n32 = lane & 31, h = lane >> 5;
-    const unsigned smem_byte = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const int lds0 = (int)smem_byte;
-
-    const int per_problem = a.row_blocks * a.col_splits;
-    const int problem = a.problem_base + (int)blockIdx.x / per_problem;
-    const int rem = (int)blockIdx.x - (problem - a.problem_base) * per_problem;
-    const int rb = a.sp_major ? rem % a.row_blocks : rem / a.col_splits;
-    const int sp = a.sp_major ? rem / a.row_blocks : rem - rb * a.col_splits;
-    const int i0 = rb * 128;
-    // a.launch_blocks: workgroups per problem of the 64-row member of this launch pair -- the finalize pass reads that many
-    // entries per problem; this member fills the first per_problem of them and zeroes the rest
-    const long long bid = (long long)a.sums_base + (long long)(problem - a.problem_base) * a.launch_blocks + rem;
-
-    const _Float16* rows = reinterpret_cast<const _Float16*>(a.cols[problem]) + (long long)a.row_offset * DPAD;
-    const float* rnorm = a.cnorm[problem] + a.row_offset;
-    q_f16x8 zreg[2][2][NK];                                   // [half][block, rotated order: see mmd_q32_kernel][k-step]
-    bool row_valid[2];
-    float rnx[2];
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int row = i0 + 64 * hb + 32 * (b ^ wr) + n32;
-            const _Float16* zp = rows + (long long)row * DPAD + wave * SW + 8 * h;
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                if (row < a.n_rows) zreg[hb][b][ks] = *reinterpret_cast<const q_f16x8*>(zp + 16 * ks);
-                else zreg[hb][b][ks] = q_f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
-        const int my_row = i0 + 64 * hb + 32 * wr + n32;
-        row_valid[hb] = my_row < a.n_rows;
-        rnx[hb] = row_valid[hb] ? -rnorm[my_row] * a.inv_d2 : 0.f;
-    }
-    const SplitScales ss = split_scales(*a.split_amax);
-    const float c1 = 2.f * ss.inv_s2 * a.inv_d2;
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) asm volatile("" : "+v"(zreg[hb][b][ks]));
-        asm volatile("" : "+v"(rnx[hb]));
-    }
-    f32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-    asm volatile("" : "+v"(zero16));
-
-    // steps of 32 points (mmd_pipe_sum_kernel: problem 0 = z rows against both sets; problem 1 = y rows against the priors,
-    // all of them or, sym, each unordered pair of 64-point blocks once with weight 2 off the diagonal)
-    const int nS = a.tiles_per_set / 2;
-    const int nJ = nS / SPB;
-    const bool sym = problem == 1 && a.sym;
-    const int blkI = (a.row_offset >> 7) + rb;             // 128-row / 128-point blocks throughout
-    const int jlo = (int)((long long)sp * nJ / a.col_splits), jhi = (int)((long long)(sp + 1) * nJ / a.col_splits);
-    const int aend = blkI < jhi ? blkI : jhi;
-    const int ja0 = jlo + ((jlo ^ (blkI + 1)) & 1);
-    const int nA = aend > ja0 ? (aend - ja0 + 1) >> 1 : 0;
-    const int nB = (blkI >= jlo && blkI < jhi) ? 1 : 0;
-    const int cbeg = blkI + 1 > jlo ? blkI + 1 : jlo;
-    const int jc0 = cbeg + ((cbeg ^ blkI) & 1);
-    const int nC = jhi > jc0 ? (jhi - jc0 + 1) >> 1 : 0;
-    const long long total = problem == 0 ? 2ll * nS : (long long)nS;
-    const long long base = problem == 0 ? 0 : nS;
-    const int sb = sym ? 0 : (int)(base + sp * total / a.col_splits);
-    const int se = sym ? (nA + nB + nC) * SPB : (int)(base + (sp + 1) * total / a.col_splits);
-    const int nsteps = se - sb;
-
-    struct Meta { int set, p0; float w; };
-    auto step_meta = [&](int v) __attribute__((always_inline)) -> Meta {
-        const int u = v < se ? v : se - 1;
-        if (sym) {
-            const int blk = u / SPB, sub = u - blk * SPB;
-            const int J = blk < nA ? ja0 + 2 * blk : (blk < nA + nB ? blkI : jc0 + 2 * (blk - nA - nB));
-            return Meta{1, J * 128 + sub * P, J != blkI ? 2.f : 1.f};
-        }
-        const int set = u >= nS ? 1 : 0;
-        return Meta{set, (u - (set ? nS : 0)) * P, 1.f};
-    };
-    struct Src { const _Float16* x; const float* nrm; };
-    const _Float16* const cbase0 = reinterpret_cast<const _Float16*>(a.cols[0]) + wave * SW;
-    const _Float16* const cbase1 = reinterpret_cast<const _Float16*>(a.cols[1]) + wave * SW;
-    const float* const nbase0 = a.cnorm[0];
-    const float* const nbase1 = a.cnorm[1];
-    auto step_src = [&](int v) __attribute__((always_inline)) -> Src {
-        const Meta m = step_meta(v);
-        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(m.p0) * (unsigned)DPAD;
-        return Src{(m.set ? cbase1 : cbase0) + off, (m.set ? nbase1 : nbase0) + m.p0};
-    };
-
-    unsigned dma_voff0, dma_voff1;
-    {
-        const int r = lane >> 2, pos = lane & 3;
-        dma_voff0 = (unsigned)(r * DPAD + 8 * (pos ^ q32_swz(r >> 2))) * 2u;
-        dma_voff1 = (unsigned)((16 + r) * DPAD + 8 * (pos ^ q32_swz(4 + (r >> 2)))) * 2u - 1024u;
-    }
-    int gram_off[2];
-    {
-        const int pa = n32 ^ (16 * wp);
-#pragma unroll
-        for (int par = 0; par < 2; ++par)
-            gram_off[par] = 1024 * (pa >> 4) + 64 * (pa & 15) + 16 * ((2 * par + h) ^ q32_swz(pa >> 2));
-    }
-    auto xbuf_byte = [&](int b) __attribute__((always_inline)) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
-    auto stage_norms = [&](const Src& X, int ring) __attribute__((always_inline)) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(L::NORM_OFF + (ring * 4 + wave) * 64 * 4));
-        dma4(uniform_ptr(X.nrm), (unsigned)lane * 4u, dst);
-    };
-    auto dma_block = [&](const Src& X, int b, int s) __attribute__((always_inline)) {
-        dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff0, dma_voff1, smem_byte + xbuf_byte(b) + 2048u * s);
-    };
-    int xw_off[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int b = c < 2 ? 1 : 0, hf = c == 0 ? 0 : 1;
-        const int owner = 2 * (b ^ wr) + (hf ^ wp);
-        xw_off[c] = lds0 + L::XCH_OFF + lane * 16 + ((owner * 3 + ((wave - owner - 1) & 3)) * 2) * 1024;
-    }
-    const int xr_off = lds0 + L::XCH_OFF + lane * 16 + wave * 3 * 2 * 1024;
-    const int nr_off = lds0 + L::NORM_OFF + (wave * 64 + 16 * wp + 4 * h) * 4;
-
-    f32x16 S[2];
-    q_f16x8 ab[RING];
-    float xv[8], fsv[8], fcn[8], pe[8];
-    f32x4 part[2][3], cn[2];
-    double sum0 = 0.0, sum1 = 0.0;
-    float fq0 = 0.f, fq1 = 0.f;
-    auto flush_sums = [&]() __attribute__((always_inline)) {
-        sum0 += (double)fq0; sum1 += (double)fq1;
-        fq0 = 0.f; fq1 = 0.f;
-    };
-
-    // one interval: Gram of the step in buffer b (tile k + 1), refilled behind pass 1 with step Xr (norms into ring slot
-    // ring_r); the partial sums of step k (exchange buffer xb_rd, norms in ring slot ring_e, meta m) are finished and summed
-    // between the matrix instructions; the partial sums of the Gram go to exchange buffer xb_wr.
-    // idx list of the vector work, operation-major over the eight entries of a lane:
-    //   [0, 40)  finishing (op 0: norm term; 1-3: own + three remote partials; 4: x)
-    //   [40, 72) Q(x) = y (1/2 + x/6 + y/24), y = x^2, SUMMED as it is formed: four fused-multiply-add chains of two entries
-    //            (only the sum over the lane's entries is needed here; truncation as in mmd_q32_kernel)
-    constexpr int VOPS = 72;
-    float e4[4];
-    auto v_op = [&](int idx, float rnx_f) __attribute__((always_inline)) {
-        if (idx < 40) {
-            const int r = idx & 7, op = idx >> 3;
-            if (op == 0) fcn[r] = fmaf(cn[r >> 2][r & 3], -a.inv_d2, rnx_f);
-            else if (op == 1) fsv[r] = S[0][r] + part[r >> 2][0][r & 3];
-            else if (op == 2) fsv[r] = fsv[r] + part[r >> 2][1][r & 3];
-            else if (op == 3) fsv[r] = fsv[r] + part[r >> 2][2][r & 3];
-            else xv[r] = fmaf(c1, fsv[r], fcn[r]);
-        } else {
-            const int el = (idx - 40) & 7, op = (idx - 40) >> 3;
-            const float x = xv[el];
-            if (op == 0) pe[el] = fmaf(1.f / 6.f, x, 0.5f);
-            else if (op == 1) fcn[el] = x * x;
-            else if (op == 2) pe[el] = fmaf(1.f / 24.f, fcn[el], pe[el]);
-            else e4[el & 3] = el < 4 ? pe[el] * fcn[el] : fmaf(pe[el], fcn[el], e4[el & 3]);
-        }
-    };
-    // the own partial S[0][0..7] of step k is consumed by op 1 above; the Gram of step k + 1 overwrites S[0] in pass 1 (slots
-    // NK ..): op 1 has to be placed before slot NK -- the list puts idx 8 .. 15 into slots <= 5
-    constexpr int V0 = 0;                                     // first slot with vector work (the partial sums' LDS round trip before it)
-    constexpr int VSL = NS - 3 - V0;                          // vector work spread over slots V0 .. V0 + VSL - 1
-    constexpr int VW = (VOPS + VSL - 1) / VSL;
-    static_assert(V0 + (15 / VW) < LAG, "the own partial sums are read before block 0's first matrix instruction overwrites them");
-    // H: the half whose Gram this interval forms (compile time: it selects registers); the item being finished is the
-    // other half.  The step buffer is refilled behind the SECOND half's reads only.
-    auto interval = [&](auto H_, int b, const Src& Xr, int ring_r, int xb_rd, int xb_wr, int ring_e, const Meta& m, bool with_e, int slack) __attribute__((always_inline)) {
-        constexpr int H = decltype(H_)::value;
-        const int gb0 = lds0 + (int)xbuf_byte(b);
-        int gbase[2] = {gb0 + gram_off[0], gb0 + gram_off[1]};
-        asm volatile("" : "+v"(gbase[0]), "+v"(gbase[1]));
-        int xw[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { xw[c] = xw_off[c] + xb_wr * L::XCH_ONE_B; asm volatile("" : "+v"(xw[c])); }
-        auto gram_rd = [&](int ks) __attribute__((always_inline)) {
-            if ((ks & 1) == 0) wait_vmcnt_n(2 * (KB - 1 - (ks >> 1)) + slack);
-            ab[ks % RING] = Q32_LDS(const q_f16x8, gbase[ks & 1] + 2048 * (ks >> 1));
-        };
-        {
-            const int xr = xr_off + xb_rd * L::XCH_ONE_B, nr = nr_off + ring_e * 4 * 64 * 4;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int w = 0; w < 3; ++w) part[q][w] = Q32_LDS(const f32x4, xr + (w * 2 + q) * 1024);
-                cn[q] = Q32_LDS(const f32x4, nr + 8 * q * 4);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < PRE; ++t) gram_rd(t);
-        Q32_PIN();
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            constexpr int S1_DONE = Sched::first(NK - 1);
-            const int lb = Sched::lb(s), ks = Sched::ks(s);
-            S[lb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[ks % RING], zreg[H][lb][ks], ks == 0 ? zero16 : S[lb], 0, 0, 0);
-            Q32_PIN();
-#pragma unroll
-            for (int k2 = 0; k2 < NK; ++k2)
-                if (Sched::rd(k2) == s) gram_rd(k2);
-            if (H == 1 && s == Sched::rd_last()) stage_norms(Xr, ring_r);      // behind the last counted wait: the counts above stay exact
-            if (s >= V0 && s < V0 + VSL) {
-#pragma unroll
-                for (int i = 0; i < VW; ++i)
-                    if (VW * (s - V0) + i < VOPS) v_op(VW * (s - V0) + i, rnx[H ^ 1]);
-            } else if (s == V0 + VSL) {
-                // fp32 partials over eight intervals, then fp64 (flush_sums); the weight and the set are wave-uniform
-                // (interval -1 finishes whatever the exchange buffer held: a select, not a zero weight, keeps a NaN out)
-                const float es = (with_e && row_valid[H ^ 1]) ? (e4[0] + e4[1]) + (e4[2] + e4[3]) : 0.f;
-                fq0 = fmaf(es, m.set ? 0.f : m.w, fq0);
-                fq1 = fmaf(es, m.set ? m.w : 0.f, fq1);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (s == (S1_DONE + 2 + i < NS - 1 ? S1_DONE + 2 + i : NS - 1))
-                    Q32_LDS(f32x4, xw[i >> 1] + (i & 1) * 1024) = f32x4{S[1][8 * (i >> 1) + 4 * (i & 1)], S[1][8 * (i >> 1) + 4 * (i & 1) + 1],
-                                                                          S[1][8 * (i >> 1) + 4 * (i & 1) + 2], S[1][8 * (i >> 1) + 4 * (i & 1) + 3]};
-            // both k-steps of block blk are in registers: refill it with the same block of step Xr
-#pragma unroll
-            for (int blk = 0; blk < KB; ++blk)
-                if (H == 1 && Sched::refill(blk) == s) dma_block(Xr, b, blk);
-            Q32_PIN();
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            Q32_LDS(f32x4, xw[2] + q * 1024) = f32x4{S[0][8 + 4 * q], S[0][8 + 4 * q + 1], S[0][8 + 4 * q + 2], S[0][8 + 4 * q + 3]};
-    };
-
-    if (nsteps > 0) {
-        // prologue: steps sb, sb + 1 into the two buffers (norm ring slots 0, 1), then interval "-1": Gram of step sb with
-        // nothing to finish (with_e false: its sums are discarded; the registers it reads hold zeros)
-        const Src X0 = step_src(sb), X1 = step_src(sb + 1);
-        stage_norms(X0, 0);
-#pragma unroll
-        for (int s = 0; s < KB; ++s) dma_block(X0, 0, s);
-        stage_norms(X1, 1);
-#pragma unroll
-        for (int s = 0; s < KB; ++s) dma_block(X1, 1, s);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { xv[r] = 0.f; pe[r] = 0.f; fsv[r] = 0.f; fcn[r] = 0.f; e4[r & 3] = 0.f; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { S[0][r] = 0.f; S[1][r] = 0.f; }
-        wait_vmcnt<0>();
-        __syncthreads();
-        // ITEMS: item v = (step v / 2, half v % 2).  Interval v forms the Gram of item v + 1 -- step s = (v + 1) / 2 in buffer
-        // s & 1, rows of half (v + 1) % 2 -- and finishes item v; the second half's interval refills the buffer with step
-        // s + 2 (norm ring slot (s + 2) & 3).  Exchange buffers alternate per item.
-        const int nitems = 2 * nsteps;
-        auto run = [&](auto H_, int v) __attribute__((always_inline)) {
-            const int s = (v + 1) >> 1;
-            const Src Xr = step_src(sb + s + 2);
-            const Meta m = step_meta(sb + (v < 0 ? 0 : (v >> 1)));
-            // DMA in flight beside the step's own (older): the norms + 2 KB pieces of the step in the other buffer
-            interval(H_, s & 1, Xr, (s + 2) & 3, v & 1, (v + 1) & 1, ((v < 0 ? 0 : v) >> 1) & 3, m, v >= 0, 1 + 2 * KB);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        for (int v = -1; v < nitems; v += 2) {
-            run(std::integral_constant<int, 0>{}, v);
-            if (v + 1 < nitems) run(std::integral_constant<int, 1>{}, v + 1);
-            if ((v & 15) == 15) flush_sums();
-        }
-        flush_sums();
-        // the zero padding points of this workgroup's column range: out of the sums in closed form (see mmd_q32_kernel)
-        {
-            float npad[2] = {0.f, 0.f};
-#pragma unroll 1
-            for (int v = sb; v < se; ++v) {
-                const Meta m = step_meta(v);
-                if (m.p0 + P <= a.n_cols) continue;
-#pragma unroll
-                for (int el = 0; el < 8; ++el) npad[m.set] += (m.p0 + 16 * wp + 8 * (el >> 2) + 4 * h + (el & 3) >= a.n_cols) ? m.w : 0.f;
-            }
-            if (npad[0] != 0.f || npad[1] != 0.f) {
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    if (!row_valid[hb]) continue;
-                    const float x = rnx[hb];
-                    const float y = x * x;
-                    const double qp = (double)(fmaf(1.f / 24.f, y, fmaf(1.f / 6.f, x, 0.5f)) * y);
-                    sum0 -= (double)npad[0] * qp;
-                    sum1 -= (double)npad[1] * qp;
-                }
-            }
-        }
-    }
-    wait_vmcnt<0>();
-
-    __syncthreads();
-    double* red = reinterpret_cast<double*>(sm + L::XCH_OFF);
-    const double w0 = wave_sum(sum0), w1 = wave_sum(sum1);
-    if (lane == 0) { red[wave * 2 + 0] = w0; red[wave * 2 + 1] = w1; }
-    __syncthreads();
-    if (tid == 0) {
-        a.wg_sums[2 * bid + 0] = (red[0] + red[2]) + (red[4] + red[6]);
-        a.wg_sums[2 * bid + 1] = (red[1] + red[3]) + (red[5] + red[7]);
-        if (rem + per_problem < a.launch_blocks) {       // the entries only the 64-row member would have written
-            a.wg_sums[2 * (bid + per_problem) + 0] = 0.0;
-            a.wg_sums[2 * (bid + per_problem) + 1] = 0.0;
-        }
-    }
-}
-
-
 template <int KB>
 int launch_q32_sum(const MmdArgs& a, int nblocks, hipStream_t s) {
-    // 128-row member when the launch still fills the chip with it and the symmetric choice is the same for both
-    // block sizes (a.sym2: mmd.hip)
+    // the 128-row member without a K-split (mmd_q32s.hip) when the launch still fills the chip with it and the symmetric
+    // choice is the same for both block sizes (a.sym2: mmd.hip)
     const int problems = nblocks / (a.row_blocks * a.col_splits);
     const int rb2 = (a.n_rows + 127) / 128;
     if (TVAE_Q32_SUM_ROWS128 && a.sym2 == a.sym && (long long)rb2 * a.col_splits * problems >= 256) {
-        constexpr int lds_bytes = Q32SumLds<KB>::BYTES;
-        static PerDeviceOnce once2;
-        TVAE_CHECK_HIP(per_device_once(once2, [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_q32_sum2_kernel<KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       lds_bytes);
-        }));
         MmdArgs b = a;
         b.launch_blocks = a.row_blocks * a.col_splits;       // entries per problem the finalize pass reads
         b.row_blocks = rb2;
-        hipLaunchKernelGGL((mmd_q32_sum2_kernel<KB>), dim3(rb2 * a.col_splits * problems), dim3(256), lds_bytes, s, b);
-        TVAE_CHECK_HIP(hipGetLastError());
-        return TVAE_OK;
+        return launch_mmd_q32_sum3(KB, b, rb2 * a.col_splits * problems, s);
     }
     constexpr int lds_bytes = Q32SumLds<KB>::BYTES;
     static PerDeviceOnce once;
