@@ -1209,6 +1209,9 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     const int copy_elt = (bf16_tiles && !p->split) ? 2 : 4;     // split: the hi copy, then the lo copy
     p->off_zp = take((int64_t)p->n_pad * p->DPAD * copy_elt);
     p->off_yp = take((int64_t)p->n_pad * p->DPAD * copy_elt);
+    // the 32-point-step kernels touch (L2 prefetch) up to four steps past the last step of a column range: slack behind the
+    // prior's image for the range that ends with it
+    if (p->split) (void)take((int64_t)8 * 32 * p->DPAD * 2);
     p->off_zn = take((int64_t)p->n_pad * 4);
     p->off_yn = take((int64_t)p->n_pad * 4);
     p->off_colpart = take((int64_t)2 * p->nwaves * p->DPAD * (p->split ? 8 : 4));      // split: stage A's fp64 partials first

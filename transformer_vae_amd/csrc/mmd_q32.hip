@@ -139,13 +139,17 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
     const int nsteps = se - sb;
 
     // ---- per-lane constants of the LDS image ----
-    unsigned dma_voff0, dma_voff1;                            // source byte offsets of the two pieces of a block
+    // per-lane source byte offsets of the LDS-DMA of (32-feature block b, 16-point piece hh): lane = (point r, chunk position
+    // pos).  The second piece rides on the instruction offset (1 KiB further in LDS), which the hardware adds to the global
+    // address as well: taken off here, over a 1 KiB bias that the column pointers carry (cbase below)
+    unsigned dvo[KB][2];
     {
         const int r = lane >> 2, pos = lane & 3;
-        dma_voff0 = (unsigned)(r * DPAD + 8 * (pos ^ q32_swz(r >> 2))) * 2u;
-        // the second piece rides on the instruction offset (1 KiB further in LDS), which the hardware adds to the global
-        // address as well: taken off here
-        dma_voff1 = (unsigned)((16 + r) * DPAD + 8 * (pos ^ q32_swz(4 + (r >> 2)))) * 2u - 1024u;
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                dvo[b][hh] = (unsigned)((16 * hh + r) * DPAD + 32 * b + 8 * (pos ^ q32_swz(4 * hh + (r >> 2)))) * 2u + 1024u - 1024u * hh;
     }
     int gram_off[2];                                          // A operand of k-step ks: + 2048 (ks / 2), [ks & 1]
     {
@@ -182,8 +186,9 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
         p0 = (u - (set ? nS : 0)) * P;
 #endif
     };
-    const _Float16* const cbase0 = reinterpret_cast<const _Float16*>(a.cols[0]) + wave * SW;
-    const _Float16* const cbase1 = reinterpret_cast<const _Float16*>(a.cols[1]) + wave * SW;
+    // column pointers carry the wave's feature slice and the -1 KiB bias of dvo
+    const _Float16* const cbase0 = reinterpret_cast<const _Float16*>(a.cols[0]) + wave * SW - 512;
+    const _Float16* const cbase1 = reinterpret_cast<const _Float16*>(a.cols[1]) + wave * SW - 512;
     const float* const nbase0 = a.cnorm[0];
     const float* const nbase1 = a.cnorm[1];
     auto step_src = [&](int v) __attribute__((always_inline)) -> Src {
@@ -192,13 +197,28 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
         const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(p0) * (unsigned)DPAD;   // the plan keeps n_pad * DPAD < 2^31
         return Src{(set ? cbase1 : cbase0) + off, (set ? nbase1 : nbase0) + p0};
     };
+    // The refill's column stream walks [sb, se) INCREMENTALLY, branch-free: one step further per interval, over the gap
+    // between the two sets' images when it crosses nS, and no further than step se - 1 (a lone wave issues one instruction
+    // per four cycles: working a step's pointers out from its index cost ~15 scalar instructions, three times per interval).
+    const long long jump_x = (cbase1 - cbase0) - (long long)nS * (P * DPAD);      // in elements
+    const long long jump_n = (nbase1 - nbase0) - (long long)nS * P;
+    auto src_next = [&](Src& X, int& v) __attribute__((always_inline)) {
+        const int v1 = v + 1;
+        const bool in = v1 < se;
+        const bool cross = in && v1 == nS;
+        X.x += (in ? P * DPAD : 0) + (cross ? jump_x : 0ll);
+        X.nrm += (in ? P : 0) + (cross ? jump_n : 0ll);
+        v = in ? v1 : v;
+    };
     auto xbuf_byte = [&](int b) __attribute__((always_inline)) -> unsigned { return (unsigned)(b * L::XBUF_B + wave * L::SLICE_B); };
+    const unsigned nvo = (unsigned)lane * 4u;
+    const unsigned nrm_lds0 = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(L::NORM_OFF + wave * 64 * 4));
+    const unsigned dma_lds0 = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(wave * L::SLICE_B));
     auto stage_norms = [&](const Src& X, int nbuf) __attribute__((always_inline)) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(L::NORM_OFF + (nbuf * 4 + wave) * 64 * 4));
-        dma4(uniform_ptr(X.nrm), (unsigned)lane * 4u, dst);
+        q32_dma_dword(X.nrm, nvo, nrm_lds0 + (unsigned)(nbuf * 4 * 64 * 4));
     };
     auto dma_block = [&](const Src& X, int b, int s) __attribute__((always_inline)) {
-        dma16_pair(reinterpret_cast<const float*>(X.x + 32 * s), dma_voff0, dma_voff1, smem_byte + xbuf_byte(b) + 2048u * s);
+        q32_dma_pair(X.x, dvo[s][0], dvo[s][1], dma_lds0 + (unsigned)(b * L::XBUF_B) + 2048u * s);
     };
     // L2 prefetch.  The refill of a block is issued ~700-1000 cycles before its first use (the buffer holds the step under
     // the gradient until then) -- enough for an L2 hit, not for the Infinity Cache or HBM behind it (timing diagnostic with
@@ -213,14 +233,16 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
         constexpr int LPP = (SW * 2 + 127) / 128;             // 128-byte lines per point in a wave's slice
         int idx = 64 * i + lane;
         if (idx >= 32 * LPP) idx = 32 * LPP - 1;
-        pf_voff[i] = (unsigned)((idx / LPP) * DPAD * 2 + (idx % LPP) * 128);
+        // relative to the REFILL's pointer (step k + 2): PFD steps further, its 1 KiB bias taken back.  Across the gap between
+        // the sets and past the range's end these touch lines nobody needs for PFD steps -- harmless, and always inside the
+        // workspace (the images are followed by their lo copies and a slack region: mmd.hip, make_plan)
+        pf_voff[i] = (unsigned)((idx / LPP) * DPAD * 2 + (idx % LPP) * 128) + (unsigned)(PFD * P * DPAD * 2 + 1024);
     }
     float pf_sink = 0.f;
     auto l2_prefetch = [&](const Src& X) __attribute__((always_inline)) {
-        const float* sbase = uniform_ptr(reinterpret_cast<const float*>(X.x));
 #pragma unroll
         for (int i = 0; i < PF_OPS; ++i)
-            asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_voff[i]), "s"(sbase) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_voff[i]), "s"(X.x) : "memory");
     };
 
     // ------------------------------------------------------------------------------------------------------------------
@@ -368,8 +390,8 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
         else pe[el] = pe[el] * x;
     };
 
-    Src Xn2_c{};
-    int c_set_c = 0, c_p0_c = 0;
+    Src Xn2_c{};                                              // the refill's stream: step xv_c (interval k refills with step k + 2)
+    int xv_c = 0, c_set_c = 0;
 
     // ---- phase A: Gram of the step in buffer b  ||  Q of the previous step (column set x_set) into E buffer ebuf; partial sums
     // of the Gram into exchange buffer xbuf.
@@ -442,8 +464,8 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
         }
         if constexpr (WITH_E) {
             // the next interval's scalars, in the shadow of the last matrix instruction's latency
-            step_meta(sb + knext, c_set_c, c_p0_c);
-            Xn2_c = step_src(sb + knext + 2);
+            c_set_c = sb + knext >= nS ? 1 : 0;
+            src_next(Xn2_c, xv_c);
             Q32_PIN();
         }
         xch_store(Bg, 2, 0);
@@ -452,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
 
     // ---- phase C: gradient of the step in buffer b (Q pieces of ebuf; each 32-feature block refilled in place with step Xn
     // behind its matrix instructions)  ||  reduction of the next step's partial sums (exchange buffer xbuf, norms nbuf)
-    auto phase_c = [&](const Bases& Bt, const Bases& Bg, int b, const Src& Xn, const Src& Xpf) __attribute__((always_inline)) {
+    auto phase_c = [&](const Bases& Bt, const Bases& Bg, int b, const Src& Xn) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -489,7 +511,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
 #pragma unroll
         for (int t = 0; t < PRE; ++t) gram_rd(Bt, t, 0);
         Q32_PIN();
-        l2_prefetch(Xpf);
+        l2_prefetch(Xn);
         Q32_PIN();
     };
 
@@ -512,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         PHASE_MARK(2);
-        phase_c(Bc, Bn, cur, Xn2, step_src(sb + k + 2 + PFD));
+        phase_c(Bc, Bn, cur, Xn2);
         PHASE_MARK(4);
     };
 
@@ -539,8 +561,10 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
             }
             wait_vmcnt<0>();                                  // buffer 1 is read transposed at the end of phase A without a counted wait
             Q32_PIN();
-            c_set_c = 0; c_p0_c = 0;
-            Xn2_c = step_src(sb + 1);
+            c_set_c = 0;
+            xv_c = sb;
+            Xn2_c = X0;
+            src_next(Xn2_c, xv_c);                            // step sb + 1 (or sb again, if that is the last)
         }
         for (int k = -1; k < nsteps; ++k) interval(k);
         // The zero padding points of this workgroup's column range (points [n_cols, n_pad) of either set) went through the
@@ -939,11 +963,12 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum_kernel(MmdArgs a) {
 
 template <int KB>
 int launch_q32_sum(const MmdArgs& a, int nblocks, hipStream_t s) {
-    // the 128-row member without a K-split (mmd_q32s.hip) when the launch still fills the chip with it and the symmetric
-    // choice is the same for both block sizes (a.sym2: mmd.hip)
+    // the 128-row member without a K-split (mmd_q32s.hip) when the symmetric choice is the same for both block sizes
+    // (a.sym2: mmd.hip) and it has more than half a chip of workgroups: it takes 1.05x the 64-row kernel's time per
+    // workgroup for twice the rows, so it wins as soon as the 64-row launch would need a second round of workgroups
     const int problems = nblocks / (a.row_blocks * a.col_splits);
     const int rb2 = (a.n_rows + 127) / 128;
-    if (TVAE_Q32_SUM_ROWS128 && a.sym2 == a.sym && (long long)rb2 * a.col_splits * problems >= 256) {
+    if (TVAE_Q32_SUM_ROWS128 && a.sym2 == a.sym && (long long)rb2 * a.col_splits * problems > 128) {
         MmdArgs b = a;
         b.launch_blocks = a.row_blocks * a.col_splits;       // entries per problem the finalize pass reads
         b.row_blocks = rb2;

@@ -33,25 +33,6 @@ namespace {
 // image is padded to whole 128-point blocks: mmd.hip, make_plan), and the workgroup writes one wg_sums entry and zeroes the
 // entries its 64-row partner in the launch pair would have written beyond it.
 // ------------------------------------------------------------------------------------------------------------------
-// LDS-DMA of this kernel: M0 is set and LEFT (a reserved register hipcc sets itself right before any use of its own, and this
-// kernel has none: no LDS-direct, no relative moves, no GWS), and up to four 1 KiB pieces go out under one
-// setting -- the instruction offset moves the LDS address AND the global address, so the per-lane offsets carry the
-// difference (see dvo below).
-__device__ __forceinline__ void s3_dma_quad(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %4\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %2, %4 offset:2048\n\tglobal_load_lds_dwordx4 %3, %4 offset:3072"
-                 : : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_byte) : "memory");
-}
-__device__ __forceinline__ void s3_dma_pair(const void* sbase, unsigned v0, unsigned v1, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
-                 : : "v"(v0), "v"(v1), "s"(sbase), "s"(lds_byte) : "memory");
-}
-__device__ __forceinline__ void s3_dma_dword(const void* sbase, unsigned v0, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(v0), "s"(sbase), "s"(lds_byte) : "memory");
-}
-
 template <int KB>
 struct Q32Sum3Lds {
     static constexpr int SLICE_B = KB * 2048;
@@ -187,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
     };
 
     // per-lane byte offsets of the LDS-DMA of (32-feature block b, 16-point piece hh): lane = (point r, chunk position pos);
-    // + 3 KiB bias - the instruction offset the piece is issued with (s3_dma_quad)
+    // + 3 KiB bias - the instruction offset the piece is issued with (q32_dma_quad)
     unsigned dvo[KB][2];
     {
         const int r = lane >> 2, pos = lane & 3;
@@ -209,13 +190,13 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
     const unsigned nrm_lds0 = __builtin_amdgcn_readfirstlane(smem_byte + (unsigned)(L::NORM_OFF + wave * 64 * 4));
     // step `sub` of block X
     auto stage_norms = [&](const Blk& X, int sub, int ring) __attribute__((always_inline)) {
-        s3_dma_dword(X.nrm + sub * P, nvo, nrm_lds0 + (unsigned)(ring * 4 * 64 * 4));
+        q32_dma_dword(X.nrm + sub * P, nvo, nrm_lds0 + (unsigned)(ring * 4 * 64 * 4));
     };
     auto dma_group = [&](const Blk& X, int sub, int b, int g) __attribute__((always_inline)) {
         const unsigned dst = dma_lds0 + (unsigned)(b * L::XBUF_B) + 4096u * g;
         const _Float16* x = X.x + sub * (P * DPAD);
-        if (2 * g + 1 < KB) s3_dma_quad(x, dvo[2 * g][0], dvo[2 * g][1], dvo[2 * g + 1][0], dvo[2 * g + 1][1], dst);
-        else s3_dma_pair(x, dvo[2 * g][0], dvo[2 * g][1], dst);
+        if (2 * g + 1 < KB) q32_dma_quad(x, dvo[2 * g][0], dvo[2 * g][1], dvo[2 * g + 1][0], dvo[2 * g + 1][1], dst);
+        else q32_dma_pair(x, dvo[2 * g][0], dvo[2 * g][1], dst);
     };
     const int nr_off = lds0 + L::NORM_OFF + (wave * 64 + 4 * h) * 4;
 
