@@ -93,7 +93,7 @@ def mmd_roofline(mode, L, achieved, kern_ms, launches, traffic=None):
         return {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_BF16_MFMA_TFLOPS if achieved else None, "traffic": traffic,
                 "kernel": ("mmd_n16_kernel<KBN,RT,*>" if L <= 192 else
-                           "mmd_q32_kernel<KB> (gradient launch) + mmd_q32_sum3_kernel<KB> (y-y sums)" if pipe else "mmd_bf16_kernel<KB,2,*,true,*> (Q-form gradient launch)"),
+                           "mmd_q32_kernel<KB> (gradient launch) + mmd_q32_sum3_kernel<KB> (y-y sums)" if pipe else "mmd_bf16_kernel<KB,2,*,true,*> (Q-form gradient launch) + mmd_q32_sum3_kernel<KB> (y-y sums)"),
                 "kernel_ms": kern_ms, "launches_timed": launches,
                 "products_per_fp32_product": {"gram": gram_p, "gradient": grad_p},
                 "executed_per_algorithmic": split_exec,

@@ -301,7 +301,9 @@ def test_row_blocks_of_an_equal_ragged_partition_add_up(n_loc, D, kind):
 
 
 @pytest.mark.parametrize("world,n_loc,D,grad", [(1, 32837, 768, True), (1, 16500, 384, False), (2, 16512, 512, True), (2, 16500, 512, True),
-                                                (2, 16448, 640, True), (1, 33000, 256, False)])
+                                                (2, 16448, 640, True), (1, 33000, 256, False),
+                                                # D > 768: the same kernel on two step buffers, beside the 32-row gradient launch
+                                                (1, 16517, 1024, True), (1, 16500, 896, False), (2, 16512, 1024, True), (2, 16480, 1024, True)])
 def test_sum_only_launches_on_128_row_workgroups(world, n_loc, D, grad):
     """Sizes at which the sum-only launches of the split mode run mmd_q32_sum3_kernel (128 rows per workgroup, each wave
     its 32 rows against the whole step): ragged ends, the two-problem launch of a call without gradient, row blocks that are whole

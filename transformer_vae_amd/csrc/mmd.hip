@@ -1139,9 +1139,9 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     p->pipe = (pipe_ok && want_grad) ? 1 : 0;
     p->pipe_sum = (pipe_ok && (p->split || kPipeSumBf16)) ? 1 : 0;
     const int rows_wg = p->n16 ? mmd_n16_rows(p->NB) : ((p->narrow64 || p->pipe_sum) ? 64 : ROWS_PER_WG);
-    // whole 32- (64-) point blocks (symmetric y-y enumeration); 128 for the split pipelined plans, whose sum-only launch may
-    // run 128-row workgroups over 128-point blocks (mmd_q32_sum3_kernel)
-    p->n_pad = (int)align_up(n_total, (p->split && p->pipe_sum) ? 128 : rows_wg);
+    // whole 32- (64-) point blocks (symmetric y-y enumeration); 128 for the split plans on the 16-bit tile kernels, whose
+    // sum-only launch may run 128-row workgroups over 128-point blocks (mmd_q32_sum3_kernel)
+    p->n_pad = (int)align_up(n_total, (p->split && (p->pipe_sum || (bf16_tiles && p->NB > kPipeMaxKb))) ? 128 : rows_wg);
     p->row_blocks = (int)((n_rows + rows_wg - 1) / rows_wg);
     p->RT = p->n16 ? rows_wg / 16 : ((p->pipe || p->pipe_sum) ? 4 : 2);
     p->row_blocks_g = p->narrow64 ? p->row_blocks : (int)((n_rows + 16 * p->RT - 1) / (16 * p->RT));

@@ -566,6 +566,19 @@ int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
     if constexpr (SPLIT && (GRAD || (RT == 2 && KB >= 7))) {
         if (a.qflag != nullptr) {          // the pair: exactly one of the two does the work (mmd.hip, QFlag)
             if constexpr (RT == 2 && KB >= 7 && TVAE_GRAM_PRODUCTS == 2) {
+                if constexpr (!GRAD) {
+                    // sum-only launches: the 128-row kernel without a K-split (mmd_q32s.hip; two step buffers at this width)
+                    // under the conditions of mmd_q32.hip's launch_q32_sum -- same symmetric choice for both block sizes,
+                    // more than half a chip of workgroups -- and images padded to whole 128-point blocks (mmd.hip, make_plan)
+                    const int problems = nblocks / (a.row_blocks * a.col_splits);
+                    const int rb2 = (a.n_rows + 127) / 128;
+                    if (a.sym2 == a.sym && a.tiles_per_set % 8 == 0 && (long long)rb2 * a.col_splits * problems > 128) {
+                        MmdArgs b = a;
+                        b.launch_blocks = a.row_blocks * a.col_splits;
+                        b.row_blocks = rb2;
+                        return launch_mmd_q32_sum3(KB, b, rb2 * a.col_splits * problems, s);
+                    }
+                }
                 static PerDeviceOnce once_q;
                 TVAE_CHECK_HIP(per_device_once(once_q, [] {
                     return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD, SPLIT, true>),

@@ -37,7 +37,7 @@ template <int KB>
 struct Q32Sum3Lds {
     static constexpr int SLICE_B = KB * 2048;
     static constexpr int XBUF_B = 4 * SLICE_B;
-    static constexpr int NBUF = 3;
+    static constexpr int NBUF = KB <= 6 ? 3 : 2;              // step buffers (64 KB each at D = 1 024: two)
     static constexpr int NORM_OFF = NBUF * XBUF_B;            // [4 ring][4 waves][64] floats
     static constexpr int RED_OFF = NORM_OFF + 4 * 4 * 64 * 4;
     static constexpr int BYTES = RED_OFF + 8 * 8;
@@ -55,8 +55,13 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
     static_assert(BAR >= 0, "slot schedule");
     constexpr int NG = (KB + 1) / 2;                          // refill: LDS-DMA groups of two 32-feature blocks (4 KiB per wave) behind the barrier, then the norms
     constexpr int DLAST = NS - GD - 2;                        // all of it ahead of the counted wait of slot NS - GD - 1
-    constexpr int DSTRIDE = (DLAST - BAR - 1) / NG;
-    static_assert(DSTRIDE >= 1 && BAR + 1 + NG * DSTRIDE <= DLAST, "slot schedule");
+    constexpr int NBUF = L::NBUF, AHEAD = NBUF - 1;           // the refill brings step k + AHEAD
+    // three buffers: the refill has two steps to land, spread it; two buffers: it is read at the end of THIS step -- out at once
+    constexpr int DSTRIDE = NBUF == 2 ? 1 : (DLAST - BAR - 1) / NG;
+    static_assert(DSTRIDE >= 1 && BAR + 1 + NG * DSTRIDE + (NBUF == 2 ? 1 : 0) <= DLAST, "slot schedule");
+    // two buffers: the refill has most of one step (~1 us) to land, an L2 hit's worth; each wave touches the lines of ITS
+    // slice of the step one BLOCK further on with plain loads into a register nothing reads (mmd_q32_kernel, L2 prefetch)
+    constexpr int PF_OPS = NBUF == 2 ? (32 * ((SW * 2 + 127) / 128) + 63) / 64 : 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
     // register budget: the row operand alone is 8 NK registers of the 256 vector registers the finishing arithmetic can
     // address; its last ZA k-steps live in accumulation registers (a matrix instruction takes its B operand from either
     // file), the two accumulators in vector registers (-amdgpu-mfma-vgpr-form: head of the file)
-    constexpr int ZA = TVAE_S3_ZA * NK / 12;
+    constexpr int ZA = KB <= 6 ? TVAE_S3_ZA * NK / 12 : 4 * NK - 24;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -179,6 +184,20 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
                 dvo[b][hh] = (unsigned)((16 * hh + r) * DPAD + 32 * b + 8 * (pos ^ q32_swz(4 * hh + (r >> 2)))) * 2u + 3072u - (unsigned)(2048 * (b & 1) + 1024 * hh);
     }
     const unsigned nvo = (unsigned)lane * 4u;
+    unsigned pf_voff[PF_OPS > 0 ? PF_OPS : 1];
+#pragma unroll
+    for (int i = 0; i < PF_OPS; ++i) {
+        constexpr int LPP = (SW * 2 + 127) / 128;             // 128-byte lines per point in a wave's slice
+        int idx = 64 * i + lane;
+        if (idx >= 32 * LPP) idx = 32 * LPP - 1;
+        pf_voff[i] = (unsigned)((idx / LPP) * DPAD * 2 + (idx % LPP) * 128) + 3072u;
+    }
+    float pf_sink = 0.f;
+    auto l2_prefetch = [&](const _Float16* x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PF_OPS; ++i)
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(pf_voff[i]), "s"(x) : "memory");
+    };
     // operand address of (slice order j, k-step parity) within a step buffer
     int gram_off[4][2];
 #pragma unroll
@@ -227,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
     Blk prv, cur, nxt, nw;                                    // blocks B - 1 (being finished), B, B + 1 (being fetched), B + 2
     auto step = [&](auto U_, int k, int buf, int bufr, int bufn) __attribute__((always_inline)) {
         constexpr int U = decltype(U_)::value, H = U & 1;
-        constexpr int ring_r = (U + 2) & 3, ring_e = (U + 3) & 3;
+        constexpr int ring_r = (U + AHEAD) & 3, ring_e = (U + 3) & 3, sub_r = (U + AHEAD) & 3;
         const bool with_e = k > 0 && k <= nsteps;
         int gb[4][2];
         gb[0][0] = gb0[0]; gb[0][1] = gb0[1];
@@ -250,7 +269,8 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
             else if (op == 4) { pe[el] = fmaf(1.f / 24.f, yv[el], pe[el]); asm volatile("" : "+v"(pe[el])); }
             else { e4[el] = (g == 0 && U == 1) ? pe[el] * yv[el] : fmaf(pe[el], yv[el], e4[el]); asm volatile("" : "+v"(e4[el])); }   // four chains per lane over the four steps of a block
         };
-        const Blk& RB = U < 2 ? cur : nxt;                    // the block of step k + 2
+        const Blk& RB = U + AHEAD < 4 ? cur : nxt;            // the block of step k + AHEAD
+        const Blk& PB = U + AHEAD < 4 ? nxt : nw;             // ... and the one behind it (nw: worked out in step 2 of this block)
         PHASE_MARK(5);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -263,7 +283,8 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
             }
             if (s == NS - GD - 1) {
                 // step k + 1's own slice has landed: everything but the LDS-DMA issued in this step (2 KB + 1 instructions) is done
-                wait_vmcnt_n(2 * KB + 1);
+                // (two buffers: this step's LDS-DMA IS step k + 1 -- everything but the prefetches behind it)
+                wait_vmcnt_n(NBUF == 2 ? PF_OPS : 2 * KB + 1);
 #pragma unroll
                 for (int par = 0; par < 2; ++par) { gb0[par] = gram_off[0][par] + bufn * L::XBUF_B; asm volatile("" : "+v"(gb0[par])); }
             }
@@ -282,8 +303,9 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
             if (s == BAR) PHASE_MARK(2);
 #pragma unroll
             for (int g = 0; g < NG; ++g)
-                if (s == BAR + 1 + g * DSTRIDE) dma_group(RB, (U + 2) & 3, bufr, g);
-            if (s == BAR + 1 + NG * DSTRIDE) stage_norms(RB, (U + 2) & 3, ring_r);
+                if (s == BAR + 1 + g * DSTRIDE) dma_group(RB, sub_r, bufr, g);
+            if (s == BAR + 1 + NG * DSTRIDE) stage_norms(RB, sub_r, ring_r);
+            if (PF_OPS > 0 && s == BAR + 2 + NG * DSTRIDE) l2_prefetch(PB.x + sub_r * (P * DPAD));
             if (s == 2 * NK - 1) PHASE_MARK(3);
             if (s == 0) PHASE_MARK(7);
             if (s == 2) PHASE_MARK(8);
@@ -309,9 +331,11 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
         stage_norms(cur, 0, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) dma_group(cur, 0, 0, g);
-        stage_norms(cur, 1, 1);
+        if (AHEAD > 1) {
+            stage_norms(cur, 1, 1);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) dma_group(cur, 1, 1, g);
+            for (int g = 0; g < NG; ++g) dma_group(cur, 1, 1, g);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { xv[r] = 0.f; pe[r] = 0.f; fv[r] = 0.f; yv[r] = 0.f; e4[r] = 0.f; }
 #pragma unroll
@@ -326,12 +350,12 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
         cn[0] = Q32_LDS(const f32x4, nr_off);
         // iteration k forms the Gram of step k (buffer k % 3) and finishes step k - 1; one block of SPB steps per trip, and
         // one trip more than there are blocks: its first step finishes the last real step, the rest is discarded
-        int buf = 0, bufr = 2, bufn = 1;
+        int buf = 0, bufr = NBUF - 1, bufn = 1;
         auto run = [&](auto U_, int k) __attribute__((always_inline)) {
             step(U_, k, buf, bufr, bufn);
-            buf = buf == 2 ? 0 : buf + 1;
-            bufr = bufr == 2 ? 0 : bufr + 1;
-            bufn = bufn == 2 ? 0 : bufn + 1;
+            buf = buf == NBUF - 1 ? 0 : buf + 1;
+            bufr = bufr == NBUF - 1 ? 0 : bufr + 1;
+            bufn = bufn == NBUF - 1 ? 0 : bufn + 1;
         };
         for (int k = 0; k <= nsteps; k += SPB) {
             run(std::integral_constant<int, 0>{}, k);
@@ -365,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
         }
     }
     wait_vmcnt<0>();
+    asm volatile("" : "+v"(pf_sink));          // the prefetch sink stays allocated until every load has returned
 
     __syncthreads();
     double* red = reinterpret_cast<double*>(sm + L::RED_OFF);
@@ -374,9 +399,10 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_sum3_kernel(MmdArgs a) {
     if (tid == 0) {
         a.wg_sums[2 * bid + 0] = (red[0] + red[2]) + (red[4] + red[6]);
         a.wg_sums[2 * bid + 1] = (red[1] + red[3]) + (red[5] + red[7]);
-        if (rem + per_problem < a.launch_blocks) {       // the entries only the 64-row member would have written
-            a.wg_sums[2 * (bid + per_problem) + 0] = 0.0;
-            a.wg_sums[2 * (bid + per_problem) + 1] = 0.0;
+        // the entries only the other (64- or 32-row) member of the launch pair would have written
+        for (int e = rem + per_problem; e < a.launch_blocks; e += per_problem) {
+            a.wg_sums[2 * (bid - rem + e) + 0] = 0.0;
+            a.wg_sums[2 * (bid - rem + e) + 1] = 0.0;
         }
     }
 }
@@ -404,6 +430,8 @@ int launch_mmd_q32_sum3(int kb, const MmdArgs& a, int nblocks, hipStream_t s) {
         case 4: return launch_q32_sum3<4>(a, nblocks, s);
         case 5: return launch_q32_sum3<5>(a, nblocks, s);
         case 6: return launch_q32_sum3<6>(a, nblocks, s);
+        case 7: return launch_q32_sum3<7>(a, nblocks, s);
+        case 8: return launch_q32_sum3<8>(a, nblocks, s);
     }
     return fail(TVAE_ERR_ARG, "mmd: no q32 sum3 kernel for %d feature blocks", kb);
 }
