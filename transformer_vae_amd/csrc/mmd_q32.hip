@@ -62,9 +62,6 @@ struct Q32Lds {
 #ifndef TVAE_Q32_SUM_ROWS128
 #define TVAE_Q32_SUM_ROWS128 1    // sum-only launches: 128 rows per workgroup without a K-split (mmd_q32s.hip) when the launch is large enough (0: always this file's 64-row kernel)
 #endif
-#ifndef TVAE_Q32_DIAG
-#define TVAE_Q32_DIAG 0       // timing diagnostics (results are wrong): 1 no Q work, 2 no Gram operand reads, 3 no foreign stores, 4 same tile every step, 5 no finishing of the partial sums, 6 no transposed gradient operand reads
-#endif
 
 
 
@@ -180,11 +177,7 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
     auto step_meta = [&](int v, int& set, int& p0) __attribute__((always_inline)) {
         const int u = v < se ? v : se - 1;                    // past the end: the last step again (results unused)
         set = u >= nS ? 1 : 0;
-#if TVAE_Q32_DIAG == 4
-        p0 = 0 * u;           // timing diagnostic: every step fetches the same tile
-#else
         p0 = (u - (set ? nS : 0)) * P;
-#endif
     };
     // column pointers carry the wave's feature slice and the -1 KiB bias of dvo
     const _Float16* const cbase0 = reinterpret_cast<const _Float16*>(a.cols[0]) + wave * SW - 512;
@@ -423,12 +416,10 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
             }
             S[lb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[ks % RING], zreg[lb][ks], ks == 0 ? zero16 : S[lb], 0, 0, 0);
             Q32_PIN();
-#if TVAE_Q32_DIAG != 2
 #pragma unroll
             for (int k2 = 0; k2 < NK; ++k2)
                 if (Sched::rd(k2) == s) gram_rd(Bg, k2, slack);
-#endif
-            if constexpr (WITH_E && TVAE_Q32_DIAG != 1) {
+            if constexpr (WITH_E) {
                 if (s < ESL) {
 #pragma unroll
                     for (int i = 0; i < EW; ++i)
@@ -449,11 +440,9 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
                 }
             }
             // the foreign row block is complete after slot S1_DONE: its four stores two slots later (matrix-pipe latency)
-#if TVAE_Q32_DIAG != 3
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (s == (S1_DONE + 2 + i < NS - 1 ? S1_DONE + 2 + i : NS - 1)) xch_store(Bg, i >> 1, i & 1);
-#endif
             if constexpr (WITH_E) {
                 // the gradient's first operand reads (wave-private step data: legal ahead of the barrier), two per slot
 #pragma unroll
@@ -489,20 +478,16 @@ __global__ __launch_bounds__(256, 1) void mmd_q32_kernel(MmdArgs a) {
             const q_f16x8 A = __builtin_bit_cast(q_f16x8, __builtin_shufflevector(gh[blk][kk][0], gh[blk][kk][1], 0, 1, 2, 3, 4, 5, 6, 7));
             acc[blk][rbk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, Bq[kk][rbk], acc[blk][rbk], 0, 0, 0);
             Q32_PIN();
-#if TVAE_Q32_DIAG != 6
             if (blk + TDB < KB) grad_rd(Bt, blk + TDB, s & 3);
-#endif
             // block blk - 1 is dead (its matrix instructions are issued, their operand reads have completed): refill it
             if ((s & 3) == 0 && blk >= 1) dma_block(Xn, b, blk - 1);
             // the 20 finishing operations of registers 0-3 in slots 1 .. H-1, the second quad's partial sums fetched in slot H,
             // its 20 operations in slots H+2 .. (two per slot at D = 768)
 #pragma unroll
-#if TVAE_Q32_DIAG != 5
             for (int i = 0; i < 20; ++i) {
                 if (s == 1 + i / FW0) xch_finish_op(0, i);
                 if (s == FH + 2 + i / FW1) xch_finish_op(1, i);
             }
-#endif
             if (s == FH) xch_fetch(Bg, 1);
             Q32_PIN();
         }
