@@ -52,12 +52,20 @@ constexpr int STEP_P = 32;
 // traffic per flop, but 434 registers per lane = one wave per SIMD) was measured SLOWER at every width
 // (N = 32768: D = 768 11.3 ms vs 9.05 ms, D = 256 5.06 vs 4.49): with 16-cycle MFMAs the second resident
 // workgroup, which hides the exchange / expm1 / barrier phases, is worth more than the halved traffic.
-template <int KB, int RT, bool GRAD, bool SPLIT>
+#ifndef TVAE_QF_GRAM_PRODUCTS
+#define TVAE_QF_GRAM_PRODUCTS 1     // Gram products of the Q-form instances (1: hi x hi; 2: + hi x lo of the rows)
+#endif
+#ifndef TVAE_QF_TWO_WG
+#define TVAE_QF_TWO_WG 1           // two workgroups per CU for the Q-form gradient instance of the 32-row kernel at KB >= 7
+#endif
+// QF: the Q-form instance of a split launch pair never holds the lo image of the columns nor an E_lo piece in LDS
+template <int KB, int RT, bool GRAD, bool SPLIT, bool QF = false>
 struct Bf16Lds {
     static constexpr int SW = 32 * KB;                       // bf16 features per wave
     static constexpr int TPW = RT / 2;                       // S' tiles finished per wave
     static constexpr int SLICE_B = STEP_P * SW * 2;          // bytes of one wave's slice of a 32-point step (one image)
-    static constexpr int SLICE_W = (SPLIT ? 2 : 1) * SLICE_B;   // SPLIT: the hi image, then the lo image
+    static constexpr bool LO = SPLIT && !(QF && TVAE_GRAM_PRODUCTS == 2);
+    static constexpr int SLICE_W = (LO ? 2 : 1) * SLICE_B;      // LO: the hi image, then the lo image
     static constexpr int NORM_B = 4 * SLICE_W;               // [2 buf][4 waves][32] float point norms
     static constexpr int XCH_B = NORM_B + 2 * 4 * STEP_P * 4;
     static constexpr int XCH_ONE_B = 2 * RT * 3 * 64 * 16;   // [tile][3 remote sources][64 lanes] float4
@@ -65,9 +73,10 @@ struct Bf16Lds {
     static constexpr int XBUFS = GRAD ? 1 : (KB <= 6 ? 2 : 1);
     static constexpr int EBUF_B = XCH_B + XBUFS * XCH_ONE_B; // [RT row tiles][64 lanes][2 point tiles] 4 x bf16
     static constexpr int EBUF_ONE_B = RT * 64 * 16;          // SPLIT: E_hi, then E_lo
-    static constexpr int BYTES = EBUF_B + (GRAD ? (SPLIT ? 2 : 1) * EBUF_ONE_B : 0);
+    static constexpr int BYTES = EBUF_B + (GRAD ? (LO ? 2 : 1) * EBUF_ONE_B : 0);
     // two workgroups per CU when LDS and registers (<= 256 per lane) both allow it
-    static constexpr int WG_PER_CU = (!SPLIT && RT == 2 && KB <= 6) ? 2 : 1;
+    // (the Q-form gradient instance at 768 < D <= 1 024: 79 KB and, capped by the launch bounds, 256 registers)
+    static constexpr int WG_PER_CU = ((!SPLIT && RT == 2 && KB <= 6) || (TVAE_QF_TWO_WG && QF && GRAD && RT == 2 && KB >= 7 && 2 * BYTES <= 160 * 1024)) ? 2 : 1;
     static_assert(RT == 2 || RT == 4, "2 or 4 row tiles");
     static_assert(BYTES <= 160 * 1024, "bf16 tile kernel exceeds the 160 KiB LDS");
     static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses the exchange buffer");
@@ -87,14 +96,14 @@ struct Bf16Lds {
 #define TVAE_QF_GRAM_PRODUCTS 1     // Gram products of the Q-form instance: its sums carry Q = E + t, which tolerates the hi x hi Gram
 #endif
 template <int KB, int RT, bool GRAD, bool SPLIT, bool QF = false>
-__global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
+__global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT, QF>::WG_PER_CU)) void mmd_bf16_kernel(MmdArgs a) {
     static_assert(!QF || (SPLIT && TVAE_GRAM_PRODUCTS == 2), "Q-form: split launches with the two-product Gram");
     // launch pairs under the device flag (mmd.hip, QFlag): the gradient launch always; the sum-only launch of the 32-row
     // kernel's widths (KB >= 7), whose QF member differs from the other only in forming ONE Gram product
     if constexpr (SPLIT && (GRAD || (RT == 2 && KB >= 7))) {
         if (a.qflag != nullptr && (__builtin_amdgcn_readfirstlane((int)*a.qflag) != 0) != QF) return;
     }
-    using L = Bf16Lds<KB, RT, GRAD, SPLIT>;
+    using L = Bf16Lds<KB, RT, GRAD, SPLIT, QF>;
     static_assert(GRAD || RT == 2, "the symmetric y-y enumeration assumes 32-row blocks");
     constexpr int SW = L::SW, DPAD = 4 * SW, NI = 2 * KB;     // NI: 16-feature blocks per slice
     // (with the two-product Gram of mmd_common.h a sum-only launch never reads the lo copy of the columns)
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT>::WG_PER_CU)) voi
         auto gram_read = [&](int sr) {
             ab[sr][0] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * sr);
             ab[sr][1] = *reinterpret_cast<const bf16x8_t*>(xs + gram_off + 2048 * sr + 1024);
-            if constexpr (SPLIT) {
+            if constexpr (L::LO) {
                 al[sr][0] = *reinterpret_cast<const bf16x8_t*>(xs + L::SLICE_B + gram_off + 2048 * sr);
                 al[sr][1] = *reinterpret_cast<const bf16x8_t*>(xs + L::SLICE_B + gram_off + 2048 * sr + 1024);
             }
@@ -579,12 +588,14 @@ int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
                         return launch_mmd_q32_sum3(KB, b, rb2 * a.col_splits * problems, s);
                     }
                 }
+                // (its own LDS image: no lo copy of the columns, no E_lo piece -- two workgroups fit a CU)
+                constexpr int lds_q = Bf16Lds<KB, RT, GRAD, SPLIT, true>::BYTES;
                 static PerDeviceOnce once_q;
                 TVAE_CHECK_HIP(per_device_once(once_q, [] {
                     return hipFuncSetAttribute(reinterpret_cast<const void*>(&mmd_bf16_kernel<KB, RT, GRAD, SPLIT, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
                 }));
-                hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD, SPLIT, true>), dim3(nblocks), dim3(256), lds_launch, s, a);
+                hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD, SPLIT, true>), dim3(nblocks), dim3(256), lds_q, s, a);
                 TVAE_CHECK_HIP(hipGetLastError());
             } else {
                 return fail(TVAE_ERR_ARG, "mmd: no Q-form instance of the split kernel for %d feature blocks, %d row tiles", KB, RT);
