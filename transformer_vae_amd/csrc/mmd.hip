@@ -1072,6 +1072,9 @@ constexpr bool kPipeSumBf16 = TVAE_PIPE_SUM_BF16 != 0;   // bf16 mode: sum-only 
 #define TVAE_QFORM 1
 #endif
 constexpr bool kQForm = TVAE_QFORM != 0 && TVAE_GRAM_PRODUCTS == 2;        // Q-form gradient on the split pipelined path (0: E-form, three gradient products)
+#ifndef TVAE_QF32_MIN_KB
+#define TVAE_QF32_MIN_KB 7     // mmd_bf16.hip
+#endif
 constexpr int kPipeMaxKb = TVAE_PIPE_MAX_KB;    // pipelined gradient kernel up to this many feature blocks per wave (0: off)
 const Shape* pick_shape(int64_t D) {
     for (const Shape& sh : kShapes)
@@ -1175,7 +1178,7 @@ bool make_plan(int64_t n_total, int64_t n_rows, int64_t D, bool want_grad, int m
     // gradient slab per split (capped at 32 GiB).
     p->sp_major = 0;
     // Q-form gradient: the split pipelined kernels, and the split 32-row kernels of 768 < D <= 1024
-    p->qform = (kQForm && p->split && want_grad && !p->n16 && (p->pipe || (bf16_tiles && p->NB >= 7 && p->RT == 2))) ? 1 : 0;
+    p->qform = (kQForm && p->split && want_grad && !p->n16 && (p->pipe || (bf16_tiles && p->NB >= TVAE_QF32_MIN_KB && p->RT == 2))) ? 1 : 0;
     if (bf16_tiles) {
         const int64_t col_bytes = 2ll * p->n_pad * p->DPAD * (p->split ? 4 : 2);
         // the pipelined Q-form instance fetches tiles three intervals ahead into its ring and no longer cares (cfg4 size,

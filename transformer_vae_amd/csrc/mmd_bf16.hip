@@ -55,6 +55,9 @@ constexpr int STEP_P = 32;
 #ifndef TVAE_QF_GRAM_PRODUCTS
 #define TVAE_QF_GRAM_PRODUCTS 1     // Gram products of the Q-form instances (1: hi x hi; 2: + hi x lo of the rows)
 #endif
+#ifndef TVAE_QF32_MIN_KB
+#define TVAE_QF32_MIN_KB 7         // the 32-row kernel has Q-form instances from this many feature blocks per wave on (narrower: mmd_q32.hip)
+#endif
 #ifndef TVAE_QF_TWO_WG
 #define TVAE_QF_TWO_WG 1           // two workgroups per CU for the Q-form gradient instance of the 32-row kernel at KB >= 7
 #endif
@@ -76,7 +79,7 @@ struct Bf16Lds {
     static constexpr int BYTES = EBUF_B + (GRAD ? (LO ? 2 : 1) * EBUF_ONE_B : 0);
     // two workgroups per CU when LDS and registers (<= 256 per lane) both allow it
     // (the Q-form gradient instance at 768 < D <= 1 024: 79 KB and, capped by the launch bounds, 256 registers)
-    static constexpr int WG_PER_CU = ((!SPLIT && RT == 2 && KB <= 6) || (TVAE_QF_TWO_WG && QF && GRAD && RT == 2 && KB >= 7 && 2 * BYTES <= 160 * 1024)) ? 2 : 1;
+    static constexpr int WG_PER_CU = ((!SPLIT && RT == 2 && KB <= 6) || (TVAE_QF_TWO_WG && QF && GRAD && RT == 2 && KB >= TVAE_QF32_MIN_KB && 2 * BYTES <= 160 * 1024)) ? 2 : 1;
     static_assert(RT == 2 || RT == 4, "2 or 4 row tiles");
     static_assert(BYTES <= 160 * 1024, "bf16 tile kernel exceeds the 160 KiB LDS");
     static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses the exchange buffer");
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, (Bf16Lds<KB, RT, GRAD, SPLIT, QF>::WG_PER_CU))
     static_assert(!QF || (SPLIT && TVAE_GRAM_PRODUCTS == 2), "Q-form: split launches with the two-product Gram");
     // launch pairs under the device flag (mmd.hip, QFlag): the gradient launch always; the sum-only launch of the 32-row
     // kernel's widths (KB >= 7), whose QF member differs from the other only in forming ONE Gram product
-    if constexpr (SPLIT && (GRAD || (RT == 2 && KB >= 7))) {
+    if constexpr (SPLIT && (GRAD || (RT == 2 && KB >= TVAE_QF32_MIN_KB))) {
         if (a.qflag != nullptr && (__builtin_amdgcn_readfirstlane((int)*a.qflag) != 0) != QF) return;
     }
     using L = Bf16Lds<KB, RT, GRAD, SPLIT, QF>;
@@ -572,9 +575,9 @@ int launch_bf16(const MmdArgs& a, int nblocks, hipStream_t s) {
     const int lds_launch = lds_bytes + debug_lds_pad() > lds_attr ? lds_attr : lds_bytes + debug_lds_pad();
     hipLaunchKernelGGL((mmd_bf16_kernel<KB, RT, GRAD, SPLIT>), dim3(nblocks), dim3(256), lds_launch, s, a);
     TVAE_CHECK_HIP(hipGetLastError());
-    if constexpr (SPLIT && (GRAD || (RT == 2 && KB >= 7))) {
+    if constexpr (SPLIT && (GRAD || (RT == 2 && KB >= TVAE_QF32_MIN_KB))) {
         if (a.qflag != nullptr) {          // the pair: exactly one of the two does the work (mmd.hip, QFlag)
-            if constexpr (RT == 2 && KB >= 7 && TVAE_GRAM_PRODUCTS == 2) {
+            if constexpr (RT == 2 && KB >= TVAE_QF32_MIN_KB && TVAE_GRAM_PRODUCTS == 2) {
                 if constexpr (!GRAD) {
                     // sum-only launches: the 128-row kernel without a K-split (mmd_q32s.hip; two step buffers at this width)
                     // under the conditions of mmd_q32.hip's launch_q32_sum -- same symmetric choice for both block sizes,
