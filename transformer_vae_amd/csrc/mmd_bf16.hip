@@ -59,7 +59,7 @@ constexpr int STEP_P = 32;
 #define TVAE_QF32_MIN_KB 7         // the 32-row kernel has Q-form instances from this many feature blocks per wave on (narrower: mmd_q32.hip)
 #endif
 #ifndef TVAE_QF_TWO_WG
-#define TVAE_QF_TWO_WG 1           // two workgroups per CU for the Q-form gradient instance of the 32-row kernel at KB >= 7
+#define TVAE_QF_TWO_WG 1           // two workgroups per CU for the Q-form instances of the 32-row kernel at KB >= 7
 #endif
 // QF: the Q-form instance of a split launch pair never holds the lo image of the columns nor an E_lo piece in LDS
 template <int KB, int RT, bool GRAD, bool SPLIT, bool QF = false>
@@ -79,7 +79,7 @@ struct Bf16Lds {
     static constexpr int BYTES = EBUF_B + (GRAD ? (LO ? 2 : 1) * EBUF_ONE_B : 0);
     // two workgroups per CU when LDS and registers (<= 256 per lane) both allow it
     // (the Q-form gradient instance at 768 < D <= 1 024: 79 KB and, capped by the launch bounds, 256 registers)
-    static constexpr int WG_PER_CU = ((!SPLIT && RT == 2 && KB <= 6) || (TVAE_QF_TWO_WG && QF && GRAD && RT == 2 && KB >= TVAE_QF32_MIN_KB && 2 * BYTES <= 160 * 1024)) ? 2 : 1;
+    static constexpr int WG_PER_CU = ((!SPLIT && RT == 2 && KB <= 6) || (TVAE_QF_TWO_WG && QF && RT == 2 && KB >= TVAE_QF32_MIN_KB && 2 * BYTES <= 160 * 1024)) ? 2 : 1;
     static_assert(RT == 2 || RT == 4, "2 or 4 row tiles");
     static_assert(BYTES <= 160 * 1024, "bf16 tile kernel exceeds the 160 KiB LDS");
     static_assert(XCH_ONE_B >= (8 + 4 * TPW * 16) * 8, "final reduction reuses the exchange buffer");
